@@ -1,0 +1,79 @@
+/* rnnoise_amd.h -- additive batched C API of the MI355X RNNoise back end.
+ *
+ * The reference API (include/rnnoise.h of xiph/rnnoise, mirrored by our include/rnnoise.h)
+ * is one-frame / one-stream / synchronous (rnnoise.h:94); thousands of concurrent streams
+ * cannot be expressed through it.  These entry points are what a maintainer's
+ * FFI would bind for the throughput path.  Plain C ABI: pointers and sizes only.
+ *
+ * A "batch" is N independent 48 kHz mono streams resident on one GPU, advancing in
+ * lock-step one 480-sample frame per step.  Frame buffers are stream-major:
+ *     in / out : [n_frames][n_streams][480] float, int16-scaled like rnnoise_demo.c:56
+ *     vad      : [n_frames][n_streams]      (return value of rnnoise_process_frame)
+ *     gains    : [n_frames][n_streams][32]  raw band gains (the `g[]` local of
+ *                src/denoise.c:465 right after compute_rnn; 0 on silent frames), optional
+ */
+#ifndef RNNOISE_AMD_H
+#define RNNOISE_AMD_H
+
+#include "rnnoise.h"
+#include "rn_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RNNoiseBatch RNNoiseBatch;
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+RNNOISE_EXPORT int rnnoise_amd_device_count(void);
+
+/* Create N zero-initialised streams on `device`, all using `model` (must outlive the
+ * batch, like rnnoise_create()).  NULL on error (no GPU, bad model, out of memory).
+ * model==NULL fails: this build carries no compiled-in weights (the reference fetches
+ * them with download_model.sh; it is equivalent to a -DUSE_WEIGHTS_FILE build,
+ * src/denoise.c:298-303). */
+RNNOISE_EXPORT RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, int device);
+RNNOISE_EXPORT void rnnoise_batch_destroy(RNNoiseBatch *b);
+RNNOISE_EXPORT int rnnoise_batch_size(const RNNoiseBatch *b);
+
+/* Back to the state rnnoise_init() produces (all zeros). 0 / -1. */
+RNNOISE_EXPORT int rnnoise_batch_reset(RNNoiseBatch *b);
+
+/* Host buffers; synchronous.  vad and gains may be NULL.  in may alias out. 0 / -1. */
+RNNOISE_EXPORT int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
+                                         int n_frames);
+
+/* Device-resident buffers (same shapes, memory of the batch's device); asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = default stream).  This is the throughput path. */
+RNNOISE_EXPORT int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
+                                                float *d_gains, int n_frames, void *hip_stream);
+
+/* Portable per-stream state: RN_STATE_FLOATS 32-bit words laid out as in rn_layout.h
+ * (the 25,128 live bytes of the reference's DenoiseState).  Import requires
+ * analysis_mem == the last 480 samples of pitch_buf, which every state produced by the
+ * reference or by export satisfies; -1 otherwise. */
+RNNOISE_EXPORT int rnnoise_batch_export_state(RNNoiseBatch *b, int stream, float *state);
+RNNOISE_EXPORT int rnnoise_batch_import_state(RNNoiseBatch *b, int stream, const float *state);
+
+/* Network implementation: 0 = vector path (v_dot4 / FMA chains), 1 = batched MFMA path.
+ * Both produce identical bits. Returns the previous value, or -1 if unsupported. */
+RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);
+
+/* Weight bytes one frame touches (SURVEY 8d "W"): the numerator of the HBM-roofline
+ * fraction reported by bench.py. */
+RNNOISE_EXPORT long rnnoise_model_weight_bytes(RNNModel *model);
+
+/* Test taps for the last processed frame step: per-stream feature vectors [N][65],
+ * silence flags [N] and final pitch periods [N] (host buffers, any may be NULL). */
+RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch);
+
+/* Average device time per launch of each kernel over the calls since the last query, in
+ * milliseconds, measured with HIP events on the launch stream when timing is enabled.
+ * ms[0]=analysis, ms[1]=network, ms[2]=synthesis. */
+RNNOISE_EXPORT int rnnoise_batch_enable_timing(RNNoiseBatch *b, int on);
+RNNOISE_EXPORT int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[3], long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

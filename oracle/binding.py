@@ -41,7 +41,7 @@ def _fp(a: np.ndarray):
 def build_oracle() -> str:
     """Compile liboracle.so if missing or stale (gcc only; works on the GPU box too)."""
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("rn_oracle.c", "rn_oracle.h", "rcp_lut_x86.h")]
+    srcs = [os.path.join(HERE, f) for f in ("rn_oracle.c", "rn_oracle.h", "../rnnoise_amd/csrc/rcp_lut_x86.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so

@@ -1,0 +1,206 @@
+"""ctypes binding of librnnoise_amd.so -- the C-ABI boundary of the product.
+
+Python host-side mirror of the reference's plugin interface for this path: the names,
+argument meaning and error behaviour are those of include/rnnoise.h (drop-in, reference
+rnnoise.h:51-125) and include/rnnoise_amd.h (additive batched API).  There is no fallback:
+if the HIP library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librnnoise_amd.so")
+
+FRAME = 480
+NB_BANDS = 32
+NB_FEATURES = 65
+STATE_FLOATS = 6282
+
+_lib = None
+
+# every symbol declared in include/rnnoise.h and include/rnnoise_amd.h
+EXPORTS = [
+    "rnnoise_get_size", "rnnoise_get_frame_size", "rnnoise_init", "rnnoise_create", "rnnoise_destroy",
+    "rnnoise_process_frame", "rnnoise_model_from_buffer", "rnnoise_model_from_file",
+    "rnnoise_model_from_filename", "rnnoise_model_free",
+    "rnnoise_amd_device_count", "rnnoise_batch_create", "rnnoise_batch_destroy", "rnnoise_batch_size",
+    "rnnoise_batch_reset", "rnnoise_batch_process", "rnnoise_batch_process_device",
+    "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
+    "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
+    "rnnoise_batch_kernel_ms",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.rnnoise_get_size.restype = C.c_int
+        L.rnnoise_get_frame_size.restype = C.c_int
+        L.rnnoise_init.argtypes = [vp, vp]
+        L.rnnoise_create.restype = vp
+        L.rnnoise_create.argtypes = [vp]
+        L.rnnoise_destroy.argtypes = [vp]
+        L.rnnoise_process_frame.restype = C.c_float
+        L.rnnoise_process_frame.argtypes = [vp, fp, fp]
+        L.rnnoise_model_from_buffer.restype = vp
+        L.rnnoise_model_from_buffer.argtypes = [C.c_char_p, C.c_int]
+        L.rnnoise_model_from_filename.restype = vp
+        L.rnnoise_model_from_filename.argtypes = [C.c_char_p]
+        L.rnnoise_model_free.argtypes = [vp]
+        L.rnnoise_amd_device_count.restype = C.c_int
+        L.rnnoise_batch_create.restype = vp
+        L.rnnoise_batch_create.argtypes = [vp, C.c_int, C.c_int]
+        L.rnnoise_batch_destroy.argtypes = [vp]
+        L.rnnoise_batch_size.argtypes = [vp]
+        L.rnnoise_batch_reset.argtypes = [vp]
+        L.rnnoise_batch_process.argtypes = [vp, fp, fp, fp, fp, C.c_int]
+        L.rnnoise_batch_process_device.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+        L.rnnoise_batch_export_state.argtypes = [vp, C.c_int, fp]
+        L.rnnoise_batch_import_state.argtypes = [vp, C.c_int, fp]
+        L.rnnoise_batch_set_nn_path.argtypes = [vp, C.c_int]
+        L.rnnoise_model_weight_bytes.restype = C.c_long
+        L.rnnoise_model_weight_bytes.argtypes = [vp]
+        L.rnnoise_batch_debug_last.argtypes = [vp, fp, ip, ip]
+        L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
+        L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+class Model:
+    """RNNModel from a "DNNw" weight blob (reference: rnnoise_model_from_buffer, rnnoise.h:102)."""
+
+    def __init__(self, blob: bytes):
+        self._blob = bytes(blob)  # borrowed by the library for the model's lifetime
+        self.h = lib().rnnoise_model_from_buffer(self._blob, len(self._blob))
+        if not self.h:
+            raise ValueError("rnnoise_model_from_buffer failed")
+
+    @property
+    def weight_bytes(self) -> int:
+        w = lib().rnnoise_model_weight_bytes(self.h)
+        if w < 0:
+            raise ValueError("weight blob rejected")
+        return int(w)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rnnoise_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Batch:
+    """N concurrent streams on one GPU (include/rnnoise_amd.h)."""
+
+    def __init__(self, model: Model, n_streams: int, device: int = 0):
+        self.model = model
+        self.n = n_streams
+        self.h = lib().rnnoise_batch_create(model.h, n_streams, device)
+        if not self.h:
+            raise RuntimeError("rnnoise_batch_create failed (no GPU / bad model / out of memory)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rnnoise_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def reset(self):
+        if lib().rnnoise_batch_reset(self.h):
+            raise RuntimeError("reset failed")
+
+    def set_nn_path(self, path: int) -> int:
+        r = lib().rnnoise_batch_set_nn_path(self.h, path)
+        if r < 0:
+            raise RuntimeError(f"network path {path} unsupported")
+        return r
+
+    def process(self, pcm: np.ndarray, want_gains: bool = True):
+        """pcm: (T, N, 480) float32 host array -> (out, vad[T,N], gains[T,N,32])."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        T, N, F = pcm.shape
+        assert N == self.n and F == FRAME
+        out = np.empty_like(pcm)
+        vad = np.empty((T, N), np.float32)
+        gains = np.empty((T, N, NB_BANDS), np.float32) if want_gains else None
+        if lib().rnnoise_batch_process(self.h, _fp(out), _fp(pcm), _fp(vad), _fp(gains), T):
+            raise RuntimeError("rnnoise_batch_process failed")
+        return out, vad, gains
+
+    def process_device(self, d_out: int, d_in: int, d_vad: int, d_gains: int, n_frames: int, stream: int = 0):
+        """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle)."""
+        if lib().rnnoise_batch_process_device(self.h, d_out, d_in, d_vad or None, d_gains or None, n_frames,
+                                              stream or None):
+            raise RuntimeError("rnnoise_batch_process_device failed")
+
+    def export_state(self, stream: int) -> np.ndarray:
+        s = np.empty(STATE_FLOATS, np.float32)
+        if lib().rnnoise_batch_export_state(self.h, stream, _fp(s)):
+            raise RuntimeError("export_state failed")
+        return s
+
+    def import_state(self, stream: int, state: np.ndarray):
+        state = np.ascontiguousarray(state, np.float32)
+        if lib().rnnoise_batch_import_state(self.h, stream, _fp(state)):
+            raise RuntimeError("import_state failed")
+
+    def debug_last(self):
+        f = np.empty((self.n, NB_FEATURES), np.float32)
+        s = np.empty(self.n, np.int32)
+        p = np.empty(self.n, np.int32)
+        ip = C.POINTER(C.c_int)
+        if lib().rnnoise_batch_debug_last(self.h, _fp(f), s.ctypes.data_as(ip), p.ctypes.data_as(ip)):
+            raise RuntimeError("debug_last failed")
+        return f, s, p
+
+    def enable_timing(self, on: bool = True):
+        lib().rnnoise_batch_enable_timing(self.h, int(on))
+
+    def kernel_ms(self):
+        ms = (C.c_double * 3)()
+        n = C.c_long(0)
+        if lib().rnnoise_batch_kernel_ms(self.h, ms, C.byref(n)):
+            raise RuntimeError("kernel_ms failed")
+        return dict(analysis=ms[0], network=ms[1], synthesis=ms[2], launches=n.value)
+
+
+class DenoiseState:
+    """The reference's one-stream object (rnnoise_create / process_frame / destroy)."""
+
+    def __init__(self, model: Model):
+        self.model = model
+        self.h = lib().rnnoise_create(model.h)
+        if not self.h:
+            raise RuntimeError("rnnoise_create failed")
+
+    def process_frame(self, frame: np.ndarray):
+        x = np.ascontiguousarray(frame, np.float32).copy()
+        vad = lib().rnnoise_process_frame(self.h, _fp(x), _fp(x))  # in place, like rnnoise_demo.c:57
+        return x, vad
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rnnoise_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

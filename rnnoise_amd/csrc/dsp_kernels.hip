@@ -1,0 +1,666 @@
+// dsp_kernels.hip -- analysis (K1) and synthesis (K3) kernels: one wavefront owns one
+// 480-sample frame of one stream; thousands of independent streams fill the grid.
+//
+// Numerics contract (DESIGN.md "parity"): every float reduction that feeds a quantiser
+// or a discrete decision keeps the reference's summation order -- lane = accumulator /
+// lag / butterfly, serial chain over the reduction index -- and the file is compiled with
+// -ffp-contract=off so that a*b+c is fused only where the reference's AVX2 intrinsics
+// fuse.  The arithmetic follows oracle/rn_oracle.c operation by operation; reference
+// citations (paths relative to /root/reference) are repeated at each stage.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rn_dev.h"
+
+#define WAVE 64
+
+struct cpx { float r, i; };
+
+__device__ __constant__ int c_eband[RN_NB_BANDS + 2] = {
+    0,  2,  4,  6,  8,  10, 12, 15, 18,  21,  24,  28,  32,  36,  41,  47,  53,
+    60, 68, 77, 87, 98, 110, 124, 140, 157, 176, 198, 223, 251, 282, 317, 356, 400};  // src/denoise.c:63-65
+
+__device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};  // src/pitch.c:422
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) {  // src/_kiss_fft_guts.h:101-103
+  cpx m;
+  m.r = a.r * b.r - a.i * b.i;
+  m.i = a.r * b.i + a.i * b.r;
+  return m;
+}
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i}; }
+
+// digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346 on factors {5,192,3,64,4,16,4,4,4,1})
+__device__ __forceinline__ int bitrev960(int i) {
+  int j0 = i % 5, q = i / 5;
+  int j1 = q % 3; q /= 3;
+  int j2 = q & 3, j3 = (q >> 2) & 3, j4 = q >> 4;
+  return j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4;
+}
+
+// In-place 960-point forward FFT on LDS data already scaled by 1/960 and digit-reversed
+// (src/kiss_fft.c:518-564 stage order 4,4,4,3,5; butterflies :101-306).  Butterflies of a
+// stage are independent, so lanes take them round-robin; each butterfly is the reference's
+// exact expression tree.
+__device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
+  __syncthreads();
+  for (int b = lane; b < 240; b += WAVE) {  // radix-4, m=1, twiddle-free (:112-131)
+    cpx *p = F + 4 * b;
+    cpx a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    cpx s0 = csub(a0, a2), f0 = cadd(a0, a2), s1 = cadd(a1, a3);
+    cpx f2 = csub(f0, s1);
+    f0 = cadd(f0, s1);
+    cpx d = csub(a1, a3);
+    p[0] = f0;
+    p[2] = f2;
+    p[1] = {s0.r + d.i, s0.i - d.r};
+    p[3] = {s0.r - d.i, s0.i + d.r};
+  }
+  __syncthreads();
+#pragma unroll
+  for (int stage = 0; stage < 2; stage++) {  // radix-4: (m=4, fstride 60), (m=16, fstride 15) (:141-165)
+    const int m = stage ? 16 : 4, mm = 4 * m, fs = stage ? 15 : 60;
+    for (int b = lane; b < 240; b += WAVE) {
+      int i = b / m, j = b % m;
+      cpx *p = F + mm * i + j;
+      cpx s0 = cmul(p[m], tw[fs * j]);
+      cpx s1 = cmul(p[2 * m], tw[2 * fs * j]);
+      cpx s2 = cmul(p[3 * m], tw[3 * fs * j]);
+      cpx s5 = csub(p[0], s1), f0 = cadd(p[0], s1);
+      cpx s3 = cadd(s0, s2), s4 = csub(s0, s2);
+      p[2 * m] = csub(f0, s3);
+      p[0] = cadd(f0, s3);
+      p[m] = {s5.r + s4.i, s5.i - s4.r};
+      p[3 * m] = {s5.r - s4.i, s5.i + s4.r};
+    }
+    __syncthreads();
+  }
+  {  // radix-3, m=64, fstride 5 (:201-225)
+    const float epi3i = tw[5 * 64].i;
+    for (int b = lane; b < 320; b += WAVE) {
+      int i = b >> 6, j = b & 63;
+      cpx *p = F + 192 * i + j;
+      cpx s1 = cmul(p[64], tw[5 * j]);
+      cpx s2 = cmul(p[128], tw[10 * j]);
+      cpx s3 = cadd(s1, s2), s0 = csub(s1, s2);
+      cpx f0 = p[0];
+      cpx fm = {f0.r - s3.r * .5f, f0.i - s3.i * .5f};
+      s0.r *= epi3i;
+      s0.i *= epi3i;
+      p[0] = cadd(f0, s3);
+      p[128] = {fm.r + s0.i, fm.i - s0.r};
+      p[64] = {fm.r - s0.i, fm.i + s0.r};
+    }
+    __syncthreads();
+  }
+  {  // radix-5, m=192, fstride 1 (:269-302)
+    const cpx ya = tw[192], yb = tw[384];
+    for (int j = lane; j < 192; j += WAVE) {
+      cpx *p = F + j;
+      cpx s0 = p[0];
+      cpx s1 = cmul(p[192], tw[j]);
+      cpx s2 = cmul(p[384], tw[2 * j]);
+      cpx s3 = cmul(p[576], tw[3 * j]);
+      cpx s4 = cmul(p[768], tw[4 * j]);
+      cpx s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
+      cpx s5, s6, s11, s12;
+      p[0] = {s0.r + (s7.r + s8.r), s0.i + (s7.i + s8.i)};
+      s5.r = s0.r + (s7.r * ya.r + s8.r * yb.r);
+      s5.i = s0.i + (s7.i * ya.r + s8.i * yb.r);
+      s6.r = s10.i * ya.i + s9.i * yb.i;
+      s6.i = -(s10.r * ya.i + s9.r * yb.i);
+      p[192] = csub(s5, s6);
+      p[768] = cadd(s5, s6);
+      s11.r = s0.r + (s7.r * yb.r + s8.r * ya.r);
+      s11.i = s0.i + (s7.i * yb.r + s8.i * ya.r);
+      s12.r = s9.i * ya.i - s10.i * yb.i;
+      s12.i = s10.r * yb.i - s9.r * ya.i;
+      p[384] = cadd(s11, s12);
+      p[576] = csub(s11, s12);
+    }
+    __syncthreads();
+  }
+}
+
+// Band energy / correlation (src/denoise.c:90-138).  Lane k < 34 owns accumulator sum[k]:
+// first band k-1's `frac` parts in bin order, then band k's `1-frac` parts -- the exact
+// per-accumulator sequence of the reference's interleaved loop.  sums: LDS scratch [34].
+__device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float *sums,
+                                const float *__restrict__ frac_tab, int lane) {
+  if (lane < RN_NB_BANDS + 2) {
+    const int k = lane;
+    float s = 0;
+    if (k >= 1) {
+      const int b0 = c_eband[k - 1], b1 = c_eband[k];
+      for (int bin = b0; bin < b1; bin++) {
+        cpx a = X[bin], b = P[bin];
+        float tmp = a.r * b.r;
+        tmp += a.i * b.i;
+        s += frac_tab[bin] * tmp;
+      }
+    }
+    if (k <= RN_NB_BANDS) {
+      const int b0 = c_eband[k], b1 = c_eband[k + 1];
+      for (int bin = b0; bin < b1; bin++) {
+        cpx a = X[bin], b = P[bin];
+        float tmp = a.r * b.r;
+        tmp += a.i * b.i;
+        s += (1 - frac_tab[bin]) * tmp;
+      }
+    }
+    sums[k] = s;
+  }
+  __syncthreads();
+  if (lane < RN_NB_BANDS) {
+    float v = sums[lane + 1];
+    if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
+    if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
+    bandE[lane] = v;
+  }
+  __syncthreads();
+}
+
+// src/denoise.c:140-154 evaluated per bin; bins >= 400 are 0 for every caller
+__device__ __forceinline__ float interp_gain_bin(const float *bandE, int bin, const RnTablesDev &tb) {
+  if (bin >= 400) return 0.f;
+  const int i = tb.band_of_bin[bin];
+  if (i == 0) return bandE[0];
+  if (i == RN_NB_BANDS) return bandE[RN_NB_BANDS - 1];
+  const float frac = tb.band_frac[bin];
+  return (1 - frac) * bandE[i - 1] + frac * bandE[i];
+}
+
+// src/denoise.c:160-170, lane i < 32 produces out[i]
+__device__ __forceinline__ float dct_lane(const float *in, int i, const RnTablesDev &tb) {
+  float sum = 0;
+  for (int j = 0; j < RN_NB_BANDS; j++) sum += in[j] * tb.dct[j * RN_NB_BANDS + i];
+  return (float)(sum * tb.dct_scale);
+}
+
+__device__ __forceinline__ float chain_dot(const float *x, const float *y, int n) {  // src/pitch.h:132-142
+  float s = 0;
+  for (int i = 0; i < n; i++) s = s + x[i] * y[i];
+  return s;
+}
+
+// src/pitch.c:44-102 (float build).  Executed uniformly by every lane (LDS broadcasts).
+__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, int &bp0, int &bp1) {
+  float Syy = 1;
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  bp0 = 0;
+  bp1 = 1;
+  for (int j = 0; j < len; j++) Syy = Syy + y[j] * y[j];
+  for (int i = 0; i < max_pitch; i++) {
+    float xc = xcorr[i];
+    if (xc > 0) {
+      float x16 = xc * 1e-12f;
+      float num = x16 * x16;
+      if (num * bd1 > bn1 * Syy) {
+        if (num * bd0 > bn0 * Syy) {
+          bn1 = bn0; bd1 = bd0; bp1 = bp0;
+          bn0 = num; bd0 = Syy; bp0 = i;
+        } else {
+          bn1 = num; bd1 = Syy; bp1 = i;
+        }
+      }
+    }
+    Syy += y[i + len] * y[i + len] - y[i] * y[i];
+    Syy = (1 > Syy) ? 1 : Syy;
+  }
+}
+
+__device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
+  return (float)(xy / sqrt((double)(1 + xx * yy)));
+}
+
+struct AnalysisLds {
+  float pb[RN_PITCH_BUF_SIZE];  // pitch_buf after the shift (src/denoise.c:359-360)
+  float xlp[864];               // 2x decimated, LPC-whitened (src/pitch.c:146-214)
+  cpx F[RN_WINDOW_SIZE];        // FFT work area; also yy_lookup scratch
+  cpx X[RN_FREQ_SIZE + 1];      // spectrum of the current frame, kept for the X.P correlation
+  float y4[388];                // 4x decimated (src/pitch.c:309-312)
+  float xc[296];                // xcorr[] of pitch_search
+  float sums[40];               // band accumulators (34 used)
+  float Ex[RN_NB_BANDS], Ep[RN_NB_BANDS], Exp[RN_NB_BANDS], Ly[RN_NB_BANDS];
+};
+
+// ---------------------------------------------------------------------------------------------
+// K1: rnn_biquad + rnn_compute_frame_features (src/denoise.c:471-472, 347-398, 409-419)
+// grid = n_streams blocks of one wavefront.
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, int parity) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
+  float *Ex = L.Ex, *Ep = L.Ep, *Exp = L.Exp, *Ly = L.Ly, *sums = L.sums;
+
+  // ---- load: shifted pitch buffer + raw input ----
+  const float *pb_old = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
+  for (int i = lane; i < RN_PITCH_BUF_SIZE - RN_FRAME_SIZE; i += WAVE) L.pb[i] = pb_old[i + RN_FRAME_SIZE];
+  const float *xin = in + (size_t)s * RN_FRAME_SIZE;
+  for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) L.pb[RN_PITCH_BUF_SIZE - RN_FRAME_SIZE + i] = xin[i];
+  __syncthreads();
+
+  // ---- rnn_biquad (src/denoise.c:409-419, coefficients :469-470): strictly serial, in place ----
+  {
+    float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
+    const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f, b1 = 1.f;
+    float *x = L.pb + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE;
+    for (int i = 0; i < RN_FRAME_SIZE; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = x[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        float xi = v[u];
+        float yi = xi + m0;
+        m0 = (float)((double)m1 + ((double)b0 * (double)xi - (double)a0 * (double)yi));
+        m1 = (float)((double)b1 * (double)xi - (double)a1 * (double)yi);
+        v[u] = yi;
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[i + u] = v[u];
+      }
+    }
+    if (lane == 0) {
+      g.mem_hp[2 * s] = m0;
+      g.mem_hp[2 * s + 1] = m1;
+    }
+  }
+  __syncthreads();
+  {  // write the shifted pitch buffer back
+    float *pb_new = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
+    for (int i = lane; i < RN_PITCH_BUF_SIZE; i += WAVE) pb_new[i] = L.pb[i];
+  }
+
+  // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
+  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+    float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
+    float v = L.pb[RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i] * w;
+    L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+  }
+  fft960_lds(L.F, tw, lane);
+  float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
+  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
+    cpx v = L.F[i];
+    L.X[i] = v;
+    gX[2 * i] = v.r;
+    gX[2 * i + 1] = v.i;
+  }
+  __syncthreads();
+  band_accumulate(Ex, L.X, L.X, sums, tb.band_frac, lane);
+
+  // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
+  for (int i = lane; i < 864; i += WAVE) {
+    float v;
+    if (i == 0) v = .5f * (.5f * (L.pb[1]) + L.pb[0]);
+    else v = .5f * (.5f * (L.pb[2 * i - 1] + L.pb[2 * i + 1]) + L.pb[2 * i]);
+    L.xlp[i] = v;
+  }
+  __syncthreads();
+  float lpc2[5];
+  {
+    // rnn_autocorr lags 0..4 (src/celt_lpc.c:92-174): lane k owns lag k
+    float ack = 0;
+    if (lane < 5) {
+      const int k = lane;
+      float sacc = chain_dot(L.xlp, L.xlp + k, 860), d = 0;
+      for (int i = k + 860; i < 864; i++) d = d + L.xlp[i] * L.xlp[i - k];
+      ack = sacc + d;
+    }
+    float ac[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, k);
+    ac[0] *= 1.0001f;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+    // rnn_lpc order 4 (src/celt_lpc.c:38-89), uniform across lanes
+    float lpc[4] = {0, 0, 0, 0};
+    if (ac[0] != 0) {
+      float error = ac[0];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float rr = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+        rr += ac[i + 1];
+        float r = -rr / error;
+        lpc[i] = r;
+#pragma unroll
+        for (int j = 0; j < (i + 1) >> 1; j++) {
+          float t1 = lpc[j], t2 = lpc[i - 1 - j];
+          lpc[j] = t1 + r * t2;
+          lpc[i - 1 - j] = t2 + r * t1;
+        }
+        error = error - (r * r) * error;
+        if (error < .001f * ac[0]) break;
+      }
+    }
+    float tmp = 1.f;
+    const float c1 = .8f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      tmp = .9f * tmp;
+      lpc[i] = lpc[i] * tmp;
+    }
+    lpc2[0] = lpc[0] + .8f;
+    lpc2[1] = lpc[1] + c1 * lpc[0];
+    lpc2[2] = lpc[2] + c1 * lpc[1];
+    lpc2[3] = lpc[3] + c1 * lpc[2];
+    lpc2[4] = c1 * lpc[3];
+  }
+  {  // celt_fir5 in place (src/pitch.c:104-143): outputs are independent given the OLD samples
+    float r[14];
+#pragma unroll
+    for (int t = 0; t < 14; t++) {
+      int i = lane + WAVE * t;
+      float sum = 0;
+      if (i < 864) {
+        sum = L.xlp[i];
+        sum = sum + lpc2[0] * (i >= 1 ? L.xlp[i - 1] : 0.f);
+        sum = sum + lpc2[1] * (i >= 2 ? L.xlp[i - 2] : 0.f);
+        sum = sum + lpc2[2] * (i >= 3 ? L.xlp[i - 3] : 0.f);
+        sum = sum + lpc2[3] * (i >= 4 ? L.xlp[i - 4] : 0.f);
+        sum = sum + lpc2[4] * (i >= 5 ? L.xlp[i - 5] : 0.f);
+      }
+      r[t] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 14; t++) {
+      int i = lane + WAVE * t;
+      if (i < 864) L.xlp[i] = r[t];
+    }
+  }
+  __syncthreads();
+
+  // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
+  for (int j = lane; j < 387; j += WAVE) L.y4[j] = L.xlp[2 * j];
+  __syncthreads();
+  for (int lag = lane; lag < 147; lag += WAVE) L.xc[lag] = chain_dot(L.y4 + 192, L.y4 + lag, 240);
+  __syncthreads();
+  int bp0, bp1;
+  find_best_pitch(L.xc, L.y4, 240, 147, bp0, bp1);
+  __syncthreads();
+  for (int i = lane; i < 294; i += WAVE) L.xc[i] = 0;
+  __syncthreads();
+  if (lane < 10) {
+    int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
+    if (c >= 0 && c < 294) {
+      float sum = chain_dot(L.xlp + 384, L.xlp + c, 480);
+      L.xc[c] = (-1 > sum) ? -1 : sum;
+    }
+  }
+  __syncthreads();
+  find_best_pitch(L.xc, L.xlp, 480, 294, bp0, bp1);
+  int offset = 0;
+  if (bp0 > 0 && bp0 < 293) {
+    float a = L.xc[bp0 - 1], b = L.xc[bp0], c = L.xc[bp0 + 1];
+    if ((c - a) > .7f * (b - a)) offset = 1;
+    else if ((a - c) > .7f * (b - c)) offset = -1;
+  }
+  int pitch_index = RN_PITCH_MAX_PERIOD - (2 * bp0 - offset);
+
+  // ---- rnn_remove_doubling (src/pitch.c:423-528): maxperiod 384, minperiod 30, N 480 ----
+  float pgain;
+  {
+    const int maxperiod = 384, minperiod = 30, N = 480, minperiod0 = RN_PITCH_MIN_PERIOD;
+    const int *sc = c_second_check;
+    const float *x = L.xlp + maxperiod;
+    float *yyl = reinterpret_cast<float *>(L.F);  // [385]
+    float *dots = reinterpret_cast<float *>(L.F) + 400;  // [32]
+    int T0 = pitch_index / 2;
+    const int prev_period = g.last_period[s] / 2;
+    const float prev_gain = g.last_gain[s];
+    if (T0 >= maxperiod) T0 = maxperiod - 1;
+    int T = T0;
+    // all candidate dot products at once: lane 0 xx, lane 1 xy(T0), lanes 2.. (k, T1 / T1b)
+    {
+      int off = -1;
+      if (lane == 0) off = 0;
+      else if (lane == 1) off = T0;
+      else if (lane < 30) {
+        int k = 2 + ((lane - 2) >> 1);
+        int T1 = (2 * T0 + k) / (2 * k), T1b;
+        if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+        else T1b = (2 * sc[k] * T0 + k) / (2 * k);
+        off = ((lane - 2) & 1) ? T1b : T1;
+      }
+      if (off >= 0) dots[lane] = chain_dot(x, x - off, N);
+    }
+    __syncthreads();
+    const float xx = dots[0];
+    float xy = dots[1];
+    {  // yy_lookup (pitch.c:449-456): serial running energy
+      float yy = xx;
+      if (lane == 0) yyl[0] = xx;
+      for (int i = 1; i <= maxperiod; i++) {
+        yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
+        if (lane == 0) yyl[i] = (0 > yy) ? 0 : yy;
+      }
+    }
+    __syncthreads();
+    float yy = yyl[T0];
+    float best_xy = xy, best_yy = yy;
+    const float g0 = pitch_gain(xy, xx, yy);
+    float gg = g0;
+    for (int k = 2; k <= 15; k++) {
+      int T1 = (2 * T0 + k) / (2 * k), T1b;
+      if (T1 < minperiod) break;
+      if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+      else T1b = (2 * sc[k] * T0 + k) / (2 * k);
+      float xy1 = dots[2 + 2 * (k - 2)], xy2 = dots[3 + 2 * (k - 2)];
+      xy1 = .5f * (xy1 + xy2);
+      float yy1 = .5f * (yyl[T1] + yyl[T1b]);
+      float g1 = pitch_gain(xy1, xx, yy1);
+      float cont;
+      int dT = T1 - prev_period;
+      dT = dT < 0 ? -dT : dT;
+      if (dT <= 1) cont = prev_gain;
+      else if (dT <= 2 && 5 * k * k < T0) cont = .5f * prev_gain;
+      else cont = 0;
+      float thresh = (.3f > .7f * g0 - cont) ? .3f : .7f * g0 - cont;
+      if (T1 < 3 * minperiod) thresh = (.4f > .85f * g0 - cont) ? .4f : .85f * g0 - cont;
+      else if (T1 < 2 * minperiod) thresh = (.5f > .9f * g0 - cont) ? .5f : .9f * g0 - cont;
+      if (g1 > thresh) {
+        best_xy = xy1;
+        best_yy = yy1;
+        T = T1;
+        gg = g1;
+      }
+    }
+    best_xy = (0 > best_xy) ? 0 : best_xy;
+    float pg;
+    if (best_yy <= best_xy) pg = 1.f;
+    else pg = best_xy / (best_yy + 1);
+    __syncthreads();
+    if (lane < 3) dots[lane] = chain_dot(x, x - (T + lane - 1), N);
+    __syncthreads();
+    float xc0 = dots[0], xc1 = dots[1], xc2 = dots[2];
+    int off2 = 0;
+    if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
+    else if ((xc0 - xc2) > .7f * (xc1 - xc2)) off2 = -1;
+    if (pg > gg) pg = gg;
+    pitch_index = 2 * T + off2;
+    if (pitch_index < minperiod0) pitch_index = minperiod0;
+    pgain = pg;
+    __syncthreads();
+  }
+  if (lane == 0) {
+    g.last_period[s] = pitch_index;
+    g.last_gain[s] = pgain;
+    g.pitch[s] = pitch_index;
+  }
+
+  // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
+  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+    float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
+    float v = L.pb[RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i] * w;
+    L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+  }
+  fft960_lds(L.F, tw, lane);
+  float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
+  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
+    cpx v = L.F[i];
+    gP[2 * i] = v.r;
+    gP[2 * i + 1] = v.i;
+  }
+  band_accumulate(Ep, L.F, L.F, sums, tb.band_frac, lane);
+  band_accumulate(Exp, L.X, L.F, sums, tb.band_frac, lane);
+  float *gE = g.spec_E[parity] + (size_t)s * 96;
+  if (lane < RN_NB_BANDS) {
+    Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
+    gE[lane] = Ex[lane];
+    gE[32 + lane] = Ep[lane];
+    gE[64 + lane] = Exp[lane];
+  }
+  __syncthreads();
+
+  // ---- features (src/denoise.c:378-397) ----
+  float *feat = g.features + (size_t)s * 68;
+  float f_hi = 0;
+  if (lane < RN_NB_BANDS) {
+    f_hi = dct_lane(Exp, lane, tb);
+    Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
+  }
+  __syncthreads();
+  // log-energy follower + total energy: 32 serial steps, evaluated uniformly
+  float E = 0;
+  {
+    float logMax = -2, follow = -2;
+    for (int i = 0; i < RN_NB_BANDS; i++) {
+      float ly = Ly[i];
+      double t = ((double)follow - 1.5 > (double)ly) ? (double)follow - 1.5 : (double)ly;
+      ly = (float)(((double)(logMax - 7) > t) ? (double)(logMax - 7) : t);
+      logMax = (logMax > ly) ? logMax : ly;
+      follow = (float)(((double)follow - 1.5 > (double)ly) ? (double)follow - 1.5 : (double)ly);
+      E += Ex[i];
+      if (lane == 0) Ly[i] = ly;
+    }
+  }
+  __syncthreads();
+  const int silence = ((double)E < 0.04) ? 1 : 0;
+  if (lane < RN_NB_BANDS) {
+    float f_lo = dct_lane(Ly, lane, tb);
+    if (lane == 0) f_lo -= 12;
+    if (lane == 1) f_lo -= 4;
+    feat[lane] = silence ? 0.f : f_lo;
+    feat[RN_NB_BANDS + lane] = silence ? 0.f : f_hi;
+  }
+  if (lane == 0) {
+    feat[2 * RN_NB_BANDS] = silence ? 0.f : (float)(.01 * (double)(pitch_index - 300));
+    g.silence[s] = silence;
+  }
+}
+
+struct SynthLds {
+  cpx F[RN_WINDOW_SIZE];
+  cpx X[RN_FREQ_SIZE + 1];
+  float misc[192];
+};
+
+// ---------------------------------------------------------------------------------------------
+// K3: rnn_pitch_filter + gain smoothing/interpolation + frame_synthesis
+// (src/denoise.c:474-496, 421-455, 140-154, 400-407, 200-217)
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
+  const int prev = parity ^ 1;
+  const float *dX = g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE;
+  const float *dP = g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE;
+  const float *dE = g.spec_E[prev] + (size_t)s * 96;
+  const float *cE = g.spec_E[parity] + (size_t)s * 96;
+  float *r = L.misc + 0, *gsm = L.misc + 32, *newE = L.misc + 64, *norm = L.misc + 96, *sums = L.misc + 128;
+  const int silence = g.silence[s];
+
+  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) L.X[i] = {dX[2 * i], dX[2 * i + 1]};
+  if (!silence) {
+    float gi = 0;
+    if (lane < RN_NB_BANDS) {  // src/denoise.c:429-440
+      const float Exp = dE[64 + lane], Ex = dE[lane], Ep = dE[32 + lane];
+      gi = g.gains[(size_t)s * RN_NB_BANDS + lane];
+      float rv;
+      if (Exp > gi) rv = 1;
+      else rv = (float)((double)((Exp * Exp) * (1 - (gi * gi))) / (.001 + (double)((gi * gi) * (1 - (Exp * Exp)))));
+      float t = (0 > rv) ? 0 : rv;
+      t = (1 < t) ? 1 : t;
+      rv = (float)sqrt((double)t);
+      rv = (float)((double)rv * sqrt((double)Ex / (1e-8 + (double)Ep)));
+      r[lane] = rv;
+    }
+    __syncthreads();
+    for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {  // :441-445
+      float rf = interp_gain_bin(r, i, tb);
+      cpx x = L.X[i];
+      x.r += rf * dP[2 * i];
+      x.i += rf * dP[2 * i + 1];
+      L.X[i] = x;
+    }
+    __syncthreads();
+    band_accumulate(newE, L.X, L.X, sums, tb.band_frac, lane);
+    if (lane < RN_NB_BANDS) {
+      norm[lane] = (float)sqrt((double)dE[lane] / (1e-8 + (double)newE[lane]));  // :447-449
+      // gain smoothing (src/denoise.c:479-487)
+      float lastg = g.lastg[(size_t)s * RN_NB_BANDS + lane];
+      const float alpha = .6f;
+      gi = (gi > alpha * lastg) ? gi : alpha * lastg;
+      double q = (double)gi * ((double)dE[lane] + 1e-3) / ((double)cE[lane] + 1e-3);
+      g.lastg[(size_t)s * RN_NB_BANDS + lane] = (float)((1.f < q) ? 1.f : q);
+      gsm[lane] = gi;
+    }
+    __syncthreads();
+    for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {  // :450-454 then :488-493
+      float nf = interp_gain_bin(norm, i, tb);
+      float gf = interp_gain_bin(gsm, i, tb);
+      cpx x = L.X[i];
+      x.r *= nf;
+      x.i *= nf;
+      x.r *= gf;
+      x.i *= gf;
+      L.X[i] = x;
+    }
+  }
+  __syncthreads();
+  // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT
+  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+    cpx v;
+    if (i < RN_FREQ_SIZE) v = L.X[i];
+    else {
+      v = L.X[RN_WINDOW_SIZE - i];
+      v.i = -v.i;
+    }
+    L.F[bitrev960(i)] = {0.0010416667f * v.r, 0.0010416667f * v.i};
+  }
+  fft960_lds(L.F, tw, lane);
+  // window + overlap-add (src/denoise.c:400-407)
+  float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
+  float *o = out + (size_t)s * RN_FRAME_SIZE;
+  for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) {
+    const float w = tb.half_window[i];
+    float lo = (float)RN_WINDOW_SIZE * L.F[(RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE].r;   // x[i]
+    float hi = (float)RN_WINDOW_SIZE * L.F[RN_FRAME_SIZE - i].r;                       // x[480+i], window index 479-i
+    lo *= w;
+    hi *= tb.half_window[RN_FRAME_SIZE - 1 - i];
+    o[i] = lo + sm[i];
+    sm[i] = hi;
+  }
+}
+
+// host-visible launch helpers -----------------------------------------------------------------
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, const float *in, int parity,
+                                         hipStream_t st) {
+  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, in, parity);
+  return hipGetLastError();
+}
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int parity,
+                                          hipStream_t st) {
+  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, out, parity);
+  return hipGetLastError();
+}

@@ -1,0 +1,68 @@
+// rn_dev.h -- device-side data model shared by the HIP kernels and the host shim.
+//
+// Layout in HBM (one RnGroupDev per group of N streams on one GPU):
+//   every per-stream field is its own dense [N][len] fp32 array, so a wavefront that
+//   owns one stream-frame reads and writes contiguous, coalesced rows, and the batched
+//   network kernel sees (streams x features) row-major matrices.
+//   The spectra that the reference copies into delayed_* every frame
+//   (src/denoise.c:498-502) live in a 2-slot ping-pong indexed by frame parity instead:
+//   the analysis kernel writes slot[parity], the synthesis kernel reads slot[parity^1]
+//   as "delayed" -- no copy.
+//   analysis_mem (src/denoise.c:73) is not stored: it always equals the last 480 samples
+//   of the previous pitch_buf (both are the previous high-passed frame), which the
+//   analysis kernel has in LDS anyway.
+#pragma once
+#include <stdint.h>
+#include "../../include/rn_layout.h"
+
+#define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
+
+struct RnTablesDev {
+  const float *half_window;   // [480]   src/rnnoise_tables.c:570 (by formula)
+  const float *dct;           // [32*32] src/rnnoise_tables.c:669
+  const float *twiddles;      // [960*2] src/rnnoise_tables.c:77
+  const float *band_frac;     // [400]   (float)j/band_size of each bin (src/denoise.c:100)
+  const uint8_t *band_of_bin; // [400]   band index i with eband[i] <= bin < eband[i+1]
+  const uint32_t *rcp_lut;    // [2048]  x86 rcpps stand-in (oracle/rcp_capture.c)
+  double dct_scale;           // sqrt(2./22), src/denoise.c:168
+};
+
+// one linear layer of the network, repacked for the GPU (see model.cpp)
+struct RnLinearDev {
+  const float *bias;      // float layers: bias; int8 layers: subias (x86 profile, nnet_arch.h:145-147)
+  const float *fw;        // float weights, column-major W[j*N + i]
+  const float *scale;     // per-output scale (already /127, c_export/common.py:248)
+  const float *diag;      // recurrent diagonal [3*M] or null
+  const int8_t *w;        // int8 blocks, 32 bytes each = [8 rows][4 cols]
+  const int *rowsum128;   // 128 * sum_j w[i][j]  (offset that turns s8 x s8 dots into s8 x u8)
+  const int *grp_start;   // [nout/8 + 1] first block of each 8-row group
+  const uint16_t *cols;   // [nblocks] first input column of each block
+  int nin, nout;
+};
+
+struct RnModelDev {
+  RnLinearDev conv1, conv2, gru_in[3], gru_rec[3], dense_out, vad_dense;
+};
+
+struct RnGroupDev {
+  int n_streams;
+  // persistent per-stream state
+  float *mem_hp;       // [N][2]
+  float *pitch_buf;    // [N][1728]
+  float *synth_mem;    // [N][480]
+  float *last_gain;    // [N]
+  int *last_period;    // [N]
+  float *lastg;        // [N][32]
+  float *conv1_state;  // [N][130]
+  float *conv2_state;  // [N][256]
+  float *gru_state;    // [3][N][384]
+  float *spec_X[2];    // [N][RN_SPEC_STRIDE]  current / delayed by parity
+  float *spec_P[2];    // [N][RN_SPEC_STRIDE]
+  float *spec_E[2];    // [N][96] = Ex | Ep | Exp
+  // per-step scratch
+  float *features;     // [N][68] (65 used)
+  int *silence;        // [N]
+  int *pitch;          // [N]   final period (debug/tests)
+  float *gains;        // [N][32] raw network gains of the current step
+  float *vad;          // [N]
+};

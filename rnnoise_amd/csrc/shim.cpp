@@ -1,0 +1,826 @@
+// shim.cpp -- host side of librnnoise_amd.so: the rnnoise.h drop-in API, the additive
+// batched API (include/rnnoise_amd.h), the "DNNw" blob reader and the GPU re-layout of the
+// model.  Plain C ABI outward; HIP runtime inward.  No CPU compute fallback exists: every
+// entry point that needs the GPU fails loudly when there is none.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rnnoise_amd.h"
+#include "rcp_lut_x86.h"
+#include "rn_dev.h"
+
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, const float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
+extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      fprintf(stderr, "[rnnoise_amd] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -1;                                                                                       \
+    }                                                                                                  \
+  } while (0)
+
+// =============================================================================================
+// "DNNw" weight blob (reference: src/nnet.h:41-62 header, src/parse_lpcnet_weights.c:37-78
+// record walk, :80-176 per-layer size checks, src/write_weights.c:46-69 writer)
+// =============================================================================================
+namespace {
+
+struct BlobRecord {
+  std::string name;
+  int type, size;
+  const uint8_t *data;
+};
+
+struct BlobHeader {
+  char head[4];
+  int32_t version, type, size, block_size;
+  char name[44];
+};
+static_assert(sizeof(BlobHeader) == 64, "DNNw header is 64 bytes");
+
+// Walks the record stream with the reference's acceptance rules (magic/version are not
+// checked there either, parse_lpcnet_weights.c:37-52).
+bool blob_parse(const void *blob, int len, std::vector<BlobRecord> &out) {
+  const uint8_t *p = static_cast<const uint8_t *>(blob);
+  while (len > 0) {
+    if (len < 64) return false;
+    BlobHeader h;
+    memcpy(&h, p, 64);
+    if (h.block_size < h.size || h.block_size > len - 64 || h.name[43] != 0 || h.size <= 0) return false;
+    out.push_back({std::string(h.name), h.type, h.size, p + 64});
+    p += 64 + h.block_size;
+    len -= 64 + h.block_size;
+  }
+  return true;
+}
+
+const BlobRecord *blob_find(const std::vector<BlobRecord> &recs, const std::string &name, int size) {
+  for (const auto &r : recs)
+    if (r.name == name) return (size < 0 || r.size == size) ? &r : nullptr;
+  return nullptr;
+}
+
+// Host view of one layer (pointers alias the blob, like the reference's LinearLayer)
+struct HostLinear {
+  const float *bias = nullptr, *subias = nullptr, *fw = nullptr, *diag = nullptr, *scale = nullptr;
+  const int8_t *w = nullptr;
+  const int32_t *idx = nullptr;
+  int idx_words = 0, nblocks = 0, nin = 0, nout = 0;
+  bool is_int8() const { return w != nullptr; }
+};
+
+// kind: 0 float dense, 1 int8 dense, 2 int8 block-sparse, 3 int8 block-sparse + diagonal
+bool linear_from_blob(HostLinear &l, const std::vector<BlobRecord> &recs, const std::string &layer, int nin, int nout,
+                      int kind) {
+  l = HostLinear();
+  l.nin = nin;
+  l.nout = nout;
+  const BlobRecord *r;
+  if (!(r = blob_find(recs, layer + "_bias", nout * 4))) return false;
+  l.bias = reinterpret_cast<const float *>(r->data);
+  if (kind == 0) {
+    if (!(r = blob_find(recs, layer + "_weights_float", nin * nout * 4))) return false;
+    l.fw = reinterpret_cast<const float *>(r->data);
+    return true;
+  }
+  if (!(r = blob_find(recs, layer + "_subias", nout * 4))) return false;
+  l.subias = reinterpret_cast<const float *>(r->data);
+  if (!(r = blob_find(recs, layer + "_scale", nout * 4))) return false;
+  l.scale = reinterpret_cast<const float *>(r->data);
+  if (kind == 1) {
+    if (!(r = blob_find(recs, layer + "_weights_int8", nin * nout))) return false;
+    l.w = reinterpret_cast<const int8_t *>(r->data);
+    l.nblocks = (nin / 4) * (nout / 8);
+    return true;
+  }
+  if (!(r = blob_find(recs, layer + "_weights_idx", -1))) return false;
+  l.idx = reinterpret_cast<const int32_t *>(r->data);
+  l.idx_words = r->size / 4;
+  {  // index stream validation, parse_lpcnet_weights.c:98-121
+    int remain = l.idx_words, rows = nout, total = 0;
+    const int32_t *idx = l.idx;
+    while (remain > 0) {
+      int nb = *idx++;
+      if (nb < 0 || remain < nb + 1) return false;
+      for (int i = 0; i < nb; i++) {
+        int pos = *idx++;
+        if (pos < 0 || pos + 3 >= nin || (pos & 3)) return false;
+      }
+      rows -= 8;
+      remain -= nb + 1;
+      total += nb;
+    }
+    if (rows != 0) return false;
+    l.nblocks = total;
+  }
+  if (!(r = blob_find(recs, layer + "_weights_int8", 32 * l.nblocks))) return false;
+  l.w = reinterpret_cast<const int8_t *>(r->data);
+  if (kind == 3) {
+    if (!(r = blob_find(recs, layer + "_weights_diag", nout * 4))) return false;
+    l.diag = reinterpret_cast<const float *>(r->data);
+  }
+  return true;
+}
+
+struct HostModel {
+  HostLinear conv1, conv2, gru_in[3], gru_rec[3], dense_out, vad_dense;
+};
+
+// the ten layers of the default architecture and their byte-exact shapes
+// (init_rnnoise of the generated rnnoise_data.c)
+bool host_model_from_blob(HostModel &m, const void *blob, int len) {
+  std::vector<BlobRecord> recs;
+  if (!blob || len <= 0 || !blob_parse(blob, len, recs)) return false;
+  bool ok = linear_from_blob(m.conv1, recs, "conv1", RN_CONV1_K, RN_CONV1_OUT, 0) &&
+            linear_from_blob(m.conv2, recs, "conv2", RN_CONV2_K, RN_CONV2_OUT, 1);
+  for (int k = 0; k < 3 && ok; k++) {
+    std::string base = "gru" + std::to_string(k + 1);
+    ok = linear_from_blob(m.gru_in[k], recs, base + "_input", RN_GRU, RN_GRU3, 2) &&
+         linear_from_blob(m.gru_rec[k], recs, base + "_recurrent", RN_GRU, RN_GRU3, 3);
+  }
+  return ok && linear_from_blob(m.dense_out, recs, "dense_out", RN_CAT, RN_NB_BANDS, 0) &&
+         linear_from_blob(m.vad_dense, recs, "vad_dense", RN_CAT, 1, 0);
+}
+
+long linear_weight_bytes(const HostLinear &l) {
+  if (!l.is_int8()) return 4L * ((long)l.nin * l.nout + l.nout);
+  long b = 32L * l.nblocks + 8L * l.nout;  // weights + subias + scale
+  if (l.idx) b += 4L * (l.nblocks + l.nout / 8);
+  if (l.diag) b += 4L * l.nout;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device arena: one allocation, 256-byte aligned carve-outs
+// ---------------------------------------------------------------------------------------------
+struct Staging {
+  std::vector<uint8_t> bytes;
+  size_t add(const void *src, size_t n) {
+    size_t off = (bytes.size() + 255) & ~size_t(255);
+    bytes.resize(off + n);
+    if (src) memcpy(bytes.data() + off, src, n);
+    else memset(bytes.data() + off, 0, n);
+    return off;
+  }
+};
+
+struct DevLinearOffsets {
+  size_t bias = 0, fw = 0, scale = 0, diag = 0, w = 0, rowsum = 0, grp = 0, cols = 0;
+  bool has_fw = false, has_diag = false, has_cols = false, is_int8 = false;
+};
+
+DevLinearOffsets stage_linear(Staging &st, const HostLinear &l) {
+  DevLinearOffsets o;
+  o.is_int8 = l.is_int8();
+  if (!o.is_int8) {
+    o.bias = st.add(l.bias, 4 * l.nout);
+    o.fw = st.add(l.fw, 4L * l.nin * l.nout);
+    o.has_fw = true;
+    return o;
+  }
+  o.bias = st.add(l.subias, 4 * l.nout);  // x86 profile adds subias to int8 layers
+  o.scale = st.add(l.scale, 4 * l.nout);
+  o.w = st.add(l.w, 32L * l.nblocks);
+  std::vector<int32_t> rowsum(l.nout, 0), grp(l.nout / 8 + 1, 0);
+  std::vector<uint16_t> cols;
+  const int8_t *w = l.w;
+  const int32_t *idx = l.idx;
+  for (int g = 0; g < l.nout / 8; g++) {
+    int nb = idx ? *idx++ : l.nin / 4;
+    grp[g + 1] = grp[g] + nb;
+    for (int b = 0; b < nb; b++) {
+      int col = idx ? *idx++ : 4 * b;
+      cols.push_back((uint16_t)col);
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 4; c++) rowsum[8 * g + r] += w[r * 4 + c];
+      w += 32;
+    }
+  }
+  for (auto &v : rowsum) v *= 128;
+  o.rowsum = st.add(rowsum.data(), 4 * rowsum.size());
+  if (idx || true) {
+    o.grp = st.add(grp.data(), 4 * grp.size());
+    o.cols = st.add(cols.data(), 2 * cols.size());
+    o.has_cols = l.idx != nullptr;
+  }
+  if (l.diag) {
+    o.diag = st.add(l.diag, 4 * l.nout);
+    o.has_diag = true;
+  }
+  return o;
+}
+
+RnLinearDev resolve_linear(const uint8_t *base, const DevLinearOffsets &o, const HostLinear &l) {
+  RnLinearDev d;
+  memset(&d, 0, sizeof d);
+  d.nin = l.nin;
+  d.nout = l.nout;
+  d.bias = reinterpret_cast<const float *>(base + o.bias);
+  if (o.has_fw) d.fw = reinterpret_cast<const float *>(base + o.fw);
+  if (o.is_int8) {
+    d.scale = reinterpret_cast<const float *>(base + o.scale);
+    d.w = reinterpret_cast<const int8_t *>(base + o.w);
+    d.rowsum128 = reinterpret_cast<const int *>(base + o.rowsum);
+    d.grp_start = reinterpret_cast<const int *>(base + o.grp);
+    if (o.has_cols) d.cols = reinterpret_cast<const uint16_t *>(base + o.cols);
+  }
+  if (o.has_diag) d.diag = reinterpret_cast<const float *>(base + o.diag);
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// static tables by formula (reference generator: src/dump_rnnoise_tables.c:54,84-96 and
+// src/kiss_fft.c:412-419; band geometry src/denoise.c:63-65,100)
+// ---------------------------------------------------------------------------------------------
+const int kEband[RN_NB_BANDS + 2] = {0,  2,  4,  6,  8,  10, 12, 15, 18,  21,  24,  28,  32,  36,  41,  47,  53,
+                                     60, 68, 77, 87, 98, 110, 124, 140, 157, 176, 198, 223, 251, 282, 317, 356, 400};
+
+struct DeviceTables {
+  int device = -1;
+  void *mem = nullptr;
+  RnTablesDev dev{};
+};
+std::mutex g_tables_mu;
+std::vector<DeviceTables> g_tables;
+
+int tables_for_device(int device, RnTablesDev &out) {
+  std::lock_guard<std::mutex> lk(g_tables_mu);
+  for (auto &t : g_tables)
+    if (t.device == device) {
+      out = t.dev;
+      return 0;
+    }
+  std::vector<float> window(RN_FRAME_SIZE), dct(RN_NB_BANDS * RN_NB_BANDS), tw(2 * RN_WINDOW_SIZE), frac(400);
+  std::vector<uint8_t> band_of(400);
+  for (int i = 0; i < RN_FRAME_SIZE; i++) {
+    double a = .5 * M_PI * (i + .5) / RN_FRAME_SIZE;
+    window[i] = (float)sin(.5 * M_PI * sin(a) * sin(a));
+  }
+  for (int i = 0; i < RN_NB_BANDS; i++)
+    for (int j = 0; j < RN_NB_BANDS; j++) {
+      float v = (float)cos((i + .5) * j * M_PI / RN_NB_BANDS);
+      if (j == 0) v = (float)(v * sqrt(.5));
+      dct[i * RN_NB_BANDS + j] = v;
+    }
+  for (int i = 0; i < RN_WINDOW_SIZE; i++) {
+    const double pi = 3.14159265358979323846264338327;
+    double phase = (-2 * pi / RN_WINDOW_SIZE) * i;
+    tw[2 * i] = (float)cos(phase);
+    tw[2 * i + 1] = (float)sin(phase);
+  }
+  for (int b = 0; b <= RN_NB_BANDS; b++) {
+    int bs = kEband[b + 1] - kEband[b];
+    for (int j = 0; j < bs; j++) {
+      frac[kEband[b] + j] = (float)j / bs;
+      band_of[kEband[b] + j] = (uint8_t)b;
+    }
+  }
+  Staging st;
+  size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
+         o_t = st.add(tw.data(), 4 * tw.size()), o_f = st.add(frac.data(), 4 * frac.size()),
+         o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(RN_RCP_LUT_X86, sizeof RN_RCP_LUT_X86);
+  DeviceTables t;
+  t.device = device;
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipMalloc(&t.mem, st.bytes.size()));
+  HIP_OK(hipMemcpy(t.mem, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
+  const uint8_t *base = static_cast<const uint8_t *>(t.mem);
+  t.dev.half_window = reinterpret_cast<const float *>(base + o_w);
+  t.dev.dct = reinterpret_cast<const float *>(base + o_d);
+  t.dev.twiddles = reinterpret_cast<const float *>(base + o_t);
+  t.dev.band_frac = reinterpret_cast<const float *>(base + o_f);
+  t.dev.band_of_bin = base + o_b;
+  t.dev.rcp_lut = reinterpret_cast<const uint32_t *>(base + o_r);
+  t.dev.dct_scale = sqrt(2. / 22);
+  g_tables.push_back(t);
+  out = t.dev;
+  return 0;
+}
+
+struct DeviceModel {
+  int device = -1;
+  void *mem = nullptr;
+  RnModelDev dev{};
+};
+
+}  // namespace
+
+// =============================================================================================
+// public types
+// =============================================================================================
+struct RNNModel {
+  const void *const_blob = nullptr;  // borrowed (rnnoise_model_from_buffer)
+  void *blob = nullptr;              // owned (rnnoise_model_from_file)
+  int blob_len = 0;
+  FILE *file = nullptr;
+  std::mutex mu;
+  int parsed = 0;  // 0 not yet, 1 ok, -1 rejected
+  HostModel host;
+  std::vector<DeviceModel> dev;
+  RNNoiseBatch *scratch = nullptr;  // 1-stream batch behind rnnoise_process_frame
+  const void *bytes() const { return blob ? blob : const_blob; }
+};
+
+struct RNNoiseBatch {
+  RNNModel *model = nullptr;
+  int device = 0, n = 0, parity = 0, nn_path = 0;
+  void *arena = nullptr;
+  size_t arena_bytes = 0;
+  RnGroupDev g{};
+  RnModelDev m{};
+  RnTablesDev tb{};
+  float *scratch_gains = nullptr, *scratch_vad = nullptr;
+  // host-buffer staging
+  float *stage_in = nullptr, *stage_out = nullptr, *stage_vad = nullptr, *stage_gains = nullptr;
+  int stage_frames = 0;
+  // timing
+  bool timing = false;
+  struct Ev { hipEvent_t a, b; int kind; };
+  std::vector<Ev> pending, pool;
+  double ms_sum[3] = {0, 0, 0};
+  long launches = 0;
+};
+
+struct DenoiseState {  // self-contained POD: no library-owned resource (SURVEY 8b "Types")
+  uint32_t magic;
+  uint32_t pad;
+  RNNModel *model;
+  float state[RN_STATE_FLOATS];
+};
+static const uint32_t kStateMagic = 0x524e4e41u;  // "RNNA"
+
+namespace {
+
+int model_parse_locked(RNNModel *m) {
+  if (m->parsed == 0) m->parsed = host_model_from_blob(m->host, m->bytes(), m->blob_len) ? 1 : -1;
+  return m->parsed == 1 ? 0 : -1;
+}
+
+int model_on_device(RNNModel *m, int device, RnModelDev &out) {
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (model_parse_locked(m)) return -1;
+  for (auto &d : m->dev)
+    if (d.device == device) {
+      out = d.dev;
+      return 0;
+    }
+  const HostModel &h = m->host;
+  Staging st;
+  DevLinearOffsets oc1 = stage_linear(st, h.conv1), oc2 = stage_linear(st, h.conv2), ogi[3], ogr[3];
+  for (int k = 0; k < 3; k++) {
+    ogi[k] = stage_linear(st, h.gru_in[k]);
+    ogr[k] = stage_linear(st, h.gru_rec[k]);
+  }
+  DevLinearOffsets od = stage_linear(st, h.dense_out), ov = stage_linear(st, h.vad_dense);
+  DeviceModel d;
+  d.device = device;
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipMalloc(&d.mem, st.bytes.size()));
+  HIP_OK(hipMemcpy(d.mem, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
+  const uint8_t *base = static_cast<const uint8_t *>(d.mem);
+  d.dev.conv1 = resolve_linear(base, oc1, h.conv1);
+  d.dev.conv2 = resolve_linear(base, oc2, h.conv2);
+  for (int k = 0; k < 3; k++) {
+    d.dev.gru_in[k] = resolve_linear(base, ogi[k], h.gru_in[k]);
+    d.dev.gru_rec[k] = resolve_linear(base, ogr[k], h.gru_rec[k]);
+  }
+  d.dev.dense_out = resolve_linear(base, od, h.dense_out);
+  d.dev.vad_dense = resolve_linear(base, ov, h.vad_dense);
+  m->dev.push_back(d);
+  out = d.dev;
+  return 0;
+}
+
+template <typename T>
+T *carve(uint8_t *&p, size_t count) {
+  T *r = reinterpret_cast<T *>(p);
+  p += (count * sizeof(T) + 255) & ~size_t(255);
+  return r;
+}
+
+size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
+  uint8_t *p = base;
+  size_t N = n;
+  g.n_streams = n;
+  g.mem_hp = carve<float>(p, 2 * N);
+  g.pitch_buf = carve<float>(p, RN_PITCH_BUF_SIZE * N);
+  g.synth_mem = carve<float>(p, RN_FRAME_SIZE * N);
+  g.last_gain = carve<float>(p, N);
+  g.last_period = carve<int>(p, N);
+  g.lastg = carve<float>(p, RN_NB_BANDS * N);
+  g.conv1_state = carve<float>(p, 130 * N);
+  g.conv2_state = carve<float>(p, 256 * N);
+  g.gru_state = carve<float>(p, 3 * RN_GRU * N);
+  for (int k = 0; k < 2; k++) {
+    g.spec_X[k] = carve<float>(p, RN_SPEC_STRIDE * N);
+    g.spec_P[k] = carve<float>(p, RN_SPEC_STRIDE * N);
+    g.spec_E[k] = carve<float>(p, 96 * N);
+  }
+  g.features = carve<float>(p, 68 * N);
+  g.silence = carve<int>(p, N);
+  g.pitch = carve<int>(p, N);
+  g.gains = carve<float>(p, RN_NB_BANDS * N);
+  g.vad = carve<float>(p, N);
+  return (size_t)(p - base);
+}
+
+int batch_flush_timing(RNNoiseBatch *b) {
+  for (auto &e : b->pending) {
+    float ms = 0;
+    HIP_OK(hipEventSynchronize(e.b));
+    HIP_OK(hipEventElapsedTime(&ms, e.a, e.b));
+    b->ms_sum[e.kind] += ms;
+    b->pool.push_back(e);
+  }
+  b->pending.clear();
+  return 0;
+}
+
+struct ScopedEvent {
+  RNNoiseBatch *b;
+  hipStream_t st;
+  RNNoiseBatch::Ev ev{};
+  bool on;
+  ScopedEvent(RNNoiseBatch *b_, hipStream_t st_, int kind) : b(b_), st(st_), on(b_->timing) {
+    if (!on) return;
+    if (!b->pool.empty()) {
+      ev = b->pool.back();
+      b->pool.pop_back();
+    } else {
+      hipEventCreate(&ev.a);
+      hipEventCreate(&ev.b);
+    }
+    ev.kind = kind;
+    hipEventRecord(ev.a, st);
+  }
+  ~ScopedEvent() {
+    if (!on) return;
+    hipEventRecord(ev.b, st);
+    b->pending.push_back(ev);
+  }
+};
+
+}  // namespace
+
+// =============================================================================================
+// batched API
+// =============================================================================================
+extern "C" int rnnoise_amd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, int device) {
+  if (!model || n_streams <= 0) {
+    fprintf(stderr, "[rnnoise_amd] rnnoise_batch_create: a model blob is required (no compiled-in weights)\n");
+    return nullptr;
+  }
+  if (device < 0 || device >= rnnoise_amd_device_count()) {
+    fprintf(stderr, "[rnnoise_amd] no HIP device %d (visible devices: %d); there is no CPU fallback\n", device,
+            rnnoise_amd_device_count());
+    return nullptr;
+  }
+  RNNoiseBatch *b = new RNNoiseBatch();
+  b->model = model;
+  b->device = device;
+  b->n = n_streams;
+  if (model_on_device(model, device, b->m) || tables_for_device(device, b->tb)) {
+    delete b;
+    return nullptr;
+  }
+  RnGroupDev probe{};
+  b->arena_bytes = batch_layout(probe, nullptr, n_streams);
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) {
+    fprintf(stderr, "[rnnoise_amd] cannot allocate %zu bytes of HBM for %d streams\n", b->arena_bytes, n_streams);
+    delete b;
+    return nullptr;
+  }
+  batch_layout(b->g, static_cast<uint8_t *>(b->arena), n_streams);
+  b->scratch_gains = b->g.gains;
+  b->scratch_vad = b->g.vad;
+  if (rnnoise_batch_reset(b)) {
+    rnnoise_batch_destroy(b);
+    return nullptr;
+  }
+  return b;
+}
+
+extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  hipDeviceSynchronize();
+  for (auto &e : b->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto &e : b->pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  if (b->stage_in) hipFree(b->stage_in);
+  if (b->stage_out) hipFree(b->stage_out);
+  if (b->stage_vad) hipFree(b->stage_vad);
+  if (b->stage_gains) hipFree(b->stage_gains);
+  if (b->arena) hipFree(b->arena);
+  delete b;
+}
+
+extern "C" int rnnoise_batch_size(const RNNoiseBatch *b) { return b ? b->n : -1; }
+
+extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
+  if (!b) return -1;
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
+  b->parity = 0;
+  return 0;
+}
+
+extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
+  if (!b || path < 0 || path > 1) return -1;
+  int old = b->nn_path;
+  b->nn_path = path;
+  return old;
+}
+
+extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
+                                            float *d_gains, int n_frames, void *hip_stream) {
+  if (!b || !d_out || !d_in || n_frames < 0) return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  HIP_OK(hipSetDevice(b->device));
+  const size_t N = b->n;
+  for (int f = 0; f < n_frames; f++) {
+    RnGroupDev g = b->g;
+    g.vad = d_vad ? d_vad + f * N : b->scratch_vad;
+    g.gains = d_gains ? d_gains + f * N * RN_NB_BANDS : b->scratch_gains;
+    {
+      ScopedEvent ev(b, st, 0);
+      HIP_OK(rn_launch_analysis(&g, &b->tb, d_in + f * N * RN_FRAME_SIZE, b->parity, st));
+    }
+    {
+      ScopedEvent ev(b, st, 1);
+      if (b->nn_path == 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st));
+      else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st));
+    }
+    {
+      ScopedEvent ev(b, st, 2);
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, b->parity, st));
+    }
+    b->parity ^= 1;
+    b->launches += b->timing ? 1 : 0;
+  }
+  return 0;
+}
+
+extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
+                                     int n_frames) {
+  if (!b || !out || !in || n_frames < 0) return -1;
+  if (n_frames == 0) return 0;
+  HIP_OK(hipSetDevice(b->device));
+  const size_t N = b->n;
+  if (b->stage_frames < n_frames) {
+    if (b->stage_in) { hipFree(b->stage_in); hipFree(b->stage_out); hipFree(b->stage_vad); hipFree(b->stage_gains); }
+    b->stage_in = b->stage_out = b->stage_vad = b->stage_gains = nullptr;
+    b->stage_frames = 0;
+    HIP_OK(hipMalloc((void **)&b->stage_in, n_frames * N * RN_FRAME_SIZE * 4));
+    HIP_OK(hipMalloc((void **)&b->stage_out, n_frames * N * RN_FRAME_SIZE * 4));
+    HIP_OK(hipMalloc((void **)&b->stage_vad, n_frames * N * 4));
+    HIP_OK(hipMalloc((void **)&b->stage_gains, n_frames * N * RN_NB_BANDS * 4));
+    b->stage_frames = n_frames;
+  }
+  HIP_OK(hipMemcpy(b->stage_in, in, n_frames * N * RN_FRAME_SIZE * 4, hipMemcpyHostToDevice));
+  if (rnnoise_batch_process_device(b, b->stage_out, b->stage_in, b->stage_vad, b->stage_gains, n_frames, nullptr))
+    return -1;
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out, b->stage_out, n_frames * N * RN_FRAME_SIZE * 4, hipMemcpyDeviceToHost));
+  if (vad) HIP_OK(hipMemcpy(vad, b->stage_vad, n_frames * N * 4, hipMemcpyDeviceToHost));
+  if (gains) HIP_OK(hipMemcpy(gains, b->stage_gains, n_frames * N * RN_NB_BANDS * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+#define D2H(dst, src, count) HIP_OK(hipMemcpy(dst, src, (count) * 4, hipMemcpyDeviceToHost))
+#define H2D(dst, src, count) HIP_OK(hipMemcpy(dst, src, (count) * 4, hipMemcpyHostToDevice))
+
+extern "C" int rnnoise_batch_export_state(RNNoiseBatch *b, int s, float *f) {
+  if (!b || !f || s < 0 || s >= b->n) return -1;
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipDeviceSynchronize());
+  const RnGroupDev &g = b->g;
+  const size_t S = s, N = b->n;
+  const int last = b->parity ^ 1;  // slot written by the most recent frame = the "delayed" spectra
+  D2H(f + RN_OFF_PITCH_BUF, g.pitch_buf + S * RN_PITCH_BUF_SIZE, RN_PITCH_BUF_SIZE);
+  memcpy(f + RN_OFF_ANALYSIS, f + RN_OFF_PITCH_BUF + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, RN_FRAME_SIZE * 4);
+  D2H(f + RN_OFF_SYNTHESIS, g.synth_mem + S * RN_FRAME_SIZE, RN_FRAME_SIZE);
+  D2H(f + RN_OFF_LAST_GAIN, g.last_gain + S, 1);
+  D2H(f + RN_OFF_LAST_PERIOD, g.last_period + S, 1);
+  D2H(f + RN_OFF_MEM_HP, g.mem_hp + 2 * S, 2);
+  D2H(f + RN_OFF_LASTG, g.lastg + S * RN_NB_BANDS, RN_NB_BANDS);
+  D2H(f + RN_OFF_CONV1, g.conv1_state + S * 130, 130);
+  D2H(f + RN_OFF_CONV2, g.conv2_state + S * 256, 256);
+  for (int k = 0; k < 3; k++) D2H(f + RN_OFF_GRU1 + k * RN_GRU, g.gru_state + (k * N + S) * RN_GRU, RN_GRU);
+  D2H(f + RN_OFF_DELAYED_X, g.spec_X[last] + S * RN_SPEC_STRIDE, 962);
+  D2H(f + RN_OFF_DELAYED_P, g.spec_P[last] + S * RN_SPEC_STRIDE, 962);
+  D2H(f + RN_OFF_DELAYED_EX, g.spec_E[last] + S * 96, 96);
+  return 0;
+}
+
+extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f) {
+  if (!b || !f || s < 0 || s >= b->n) return -1;
+  if (memcmp(f + RN_OFF_ANALYSIS, f + RN_OFF_PITCH_BUF + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, RN_FRAME_SIZE * 4)) {
+    fprintf(stderr, "[rnnoise_amd] import_state: analysis_mem differs from the tail of pitch_buf\n");
+    return -1;
+  }
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipDeviceSynchronize());
+  const RnGroupDev &g = b->g;
+  const size_t S = s, N = b->n;
+  const int last = b->parity ^ 1;
+  H2D(g.pitch_buf + S * RN_PITCH_BUF_SIZE, f + RN_OFF_PITCH_BUF, RN_PITCH_BUF_SIZE);
+  H2D(g.synth_mem + S * RN_FRAME_SIZE, f + RN_OFF_SYNTHESIS, RN_FRAME_SIZE);
+  H2D(g.last_gain + S, f + RN_OFF_LAST_GAIN, 1);
+  H2D(g.last_period + S, f + RN_OFF_LAST_PERIOD, 1);
+  H2D(g.mem_hp + 2 * S, f + RN_OFF_MEM_HP, 2);
+  H2D(g.lastg + S * RN_NB_BANDS, f + RN_OFF_LASTG, RN_NB_BANDS);
+  H2D(g.conv1_state + S * 130, f + RN_OFF_CONV1, 130);
+  H2D(g.conv2_state + S * 256, f + RN_OFF_CONV2, 256);
+  for (int k = 0; k < 3; k++) H2D(g.gru_state + (k * N + S) * RN_GRU, f + RN_OFF_GRU1 + k * RN_GRU, RN_GRU);
+  H2D(g.spec_X[last] + S * RN_SPEC_STRIDE, f + RN_OFF_DELAYED_X, 962);
+  H2D(g.spec_P[last] + S * RN_SPEC_STRIDE, f + RN_OFF_DELAYED_P, 962);
+  H2D(g.spec_E[last] + S * 96, f + RN_OFF_DELAYED_EX, 96);
+  return 0;
+}
+
+extern "C" long rnnoise_model_weight_bytes(RNNModel *model) {
+  if (!model) return -1;
+  std::lock_guard<std::mutex> lk(model->mu);
+  if (model_parse_locked(model)) return -1;
+  const HostModel &h = model->host;
+  long w = linear_weight_bytes(h.conv1) + linear_weight_bytes(h.conv2) + linear_weight_bytes(h.dense_out) +
+           linear_weight_bytes(h.vad_dense);
+  for (int k = 0; k < 3; k++) w += linear_weight_bytes(h.gru_in[k]) + linear_weight_bytes(h.gru_rec[k]);
+  return w;
+}
+
+extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch) {
+  if (!b) return -1;
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipDeviceSynchronize());
+  if (features) {
+    std::vector<float> tmp((size_t)b->n * 68);
+    D2H(tmp.data(), b->g.features, tmp.size());
+    for (int s = 0; s < b->n; s++) memcpy(features + (size_t)s * RN_NB_FEATURES, tmp.data() + (size_t)s * 68, RN_NB_FEATURES * 4);
+  }
+  if (silence) D2H(silence, b->g.silence, b->n);
+  if (pitch) D2H(pitch, b->g.pitch, b->n);
+  return 0;
+}
+
+extern "C" int rnnoise_batch_enable_timing(RNNoiseBatch *b, int on) {
+  if (!b) return -1;
+  if (batch_flush_timing(b)) return -1;
+  b->timing = on != 0;
+  b->ms_sum[0] = b->ms_sum[1] = b->ms_sum[2] = 0;
+  b->launches = 0;
+  return 0;
+}
+
+extern "C" int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[3], long *launches) {
+  if (!b || !ms) return -1;
+  if (batch_flush_timing(b)) return -1;
+  for (int k = 0; k < 3; k++) ms[k] = b->launches ? b->ms_sum[k] / b->launches : 0.0;
+  if (launches) *launches = b->launches;
+  b->ms_sum[0] = b->ms_sum[1] = b->ms_sum[2] = 0;
+  b->launches = 0;
+  return 0;
+}
+
+// =============================================================================================
+// drop-in rnnoise.h API (reference implementation: src/denoise.c:227-325,457-504)
+// =============================================================================================
+extern "C" RNNModel *rnnoise_model_from_buffer(const void *ptr, int len) {
+  if (!ptr || len <= 0) return nullptr;
+  RNNModel *m = new RNNModel();
+  m->const_blob = ptr;
+  m->blob_len = len;
+  return m;
+}
+
+extern "C" RNNModel *rnnoise_model_from_file(FILE *f) {
+  if (!f) return nullptr;
+  if (fseek(f, 0, SEEK_END)) return nullptr;
+  long len = ftell(f);
+  if (len <= 0 || len > 0x7fffffffL || fseek(f, 0, SEEK_SET)) return nullptr;
+  void *buf = malloc(len);
+  if (!buf) return nullptr;
+  if (fread(buf, len, 1, f) != 1) {
+    free(buf);
+    return nullptr;
+  }
+  RNNModel *m = new RNNModel();
+  m->blob = buf;
+  m->blob_len = (int)len;
+  return m;
+}
+
+extern "C" RNNModel *rnnoise_model_from_filename(const char *filename) {
+  FILE *f = filename ? fopen(filename, "rb") : nullptr;
+  if (!f) return nullptr;  // the reference dereferences NULL here (denoise.c:246-248); we refuse instead
+  RNNModel *m = rnnoise_model_from_file(f);
+  if (!m) {
+    fclose(f);
+    return nullptr;
+  }
+  m->file = f;
+  return m;
+}
+
+extern "C" void rnnoise_model_free(RNNModel *model) {
+  if (!model) return;
+  if (model->scratch) rnnoise_batch_destroy(model->scratch);
+  for (auto &d : model->dev) {
+    hipSetDevice(d.device);
+    hipFree(d.mem);
+  }
+  if (model->file) fclose(model->file);
+  free(model->blob);
+  delete model;
+}
+
+extern "C" int rnnoise_get_size(void) { return (int)sizeof(DenoiseState); }
+extern "C" int rnnoise_get_frame_size(void) { return RN_FRAME_SIZE; }
+
+extern "C" int rnnoise_init(DenoiseState *st, RNNModel *model) {
+  if (!st) return -1;
+  memset(st, 0, sizeof *st);
+  if (!model) {
+    fprintf(stderr, "[rnnoise_amd] rnnoise_init(NULL model): this build has no compiled-in weights; "
+                    "load a blob with rnnoise_model_from_file()\n");
+    return -1;
+  }
+  {
+    std::lock_guard<std::mutex> lk(model->mu);
+    if (model_parse_locked(model)) return -1;
+  }
+  if (rnnoise_amd_device_count() < 1) {
+    fprintf(stderr, "[rnnoise_amd] no HIP device visible; this library has no CPU path\n");
+    return -1;
+  }
+  st->magic = kStateMagic;
+  st->model = model;
+  return 0;
+}
+
+extern "C" DenoiseState *rnnoise_create(RNNModel *model) {
+  DenoiseState *st = static_cast<DenoiseState *>(malloc(sizeof(DenoiseState)));
+  if (!st) return nullptr;
+  if (rnnoise_init(st, model)) {
+    free(st);
+    return nullptr;
+  }
+  return st;
+}
+
+extern "C" void rnnoise_destroy(DenoiseState *st) { free(st); }
+
+// One frame of one stream: stage the self-contained state into the model's 1-stream batch,
+// run the same three kernels as the batched path, stage it back.  Correct, not fast
+// (the single-frame API cannot express the parallelism the GPU needs).
+extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float *in) {
+  if (!st || st->magic != kStateMagic || !st->model || !out || !in) {
+    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: uninitialised state\n");
+    abort();
+  }
+  RNNModel *m = st->model;
+  RNNoiseBatch *b;
+  {
+    std::unique_lock<std::mutex> lk(m->mu);
+    if (!m->scratch) {
+      lk.unlock();  // rnnoise_batch_create takes the model lock itself
+      RNNoiseBatch *nb = rnnoise_batch_create(m, 1, 0);
+      lk.lock();
+      if (!m->scratch) m->scratch = nb;
+      else if (nb) rnnoise_batch_destroy(nb);
+    }
+    b = m->scratch;
+  }
+  if (!b) {
+    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: no GPU batch available (no CPU fallback)\n");
+    abort();
+  }
+  static std::mutex frame_mu;  // the scratch batch is shared by every state of this model
+  std::lock_guard<std::mutex> lk(frame_mu);
+  float vad = 0;
+  if (rnnoise_batch_import_state(b, 0, st->state) || rnnoise_batch_process(b, out, in, &vad, nullptr, 1) ||
+      rnnoise_batch_export_state(b, 0, st->state)) {
+    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: GPU step failed\n");
+    abort();
+  }
+  return vad;
+}

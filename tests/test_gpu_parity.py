@@ -1,0 +1,256 @@
+"""GPU suite: the HIP path, called through the C-ABI, against the oracle and the goldens.
+
+Bar (BASELINE.json north_star: gains within 1e-4 relative): we demand MORE -- bit-identical
+features, pitch, raw gains, VAD, PCM and exported state -- because the int8 quantisers turn
+1-ULP deviations into >1e-4 gain deviations.  The one tolerated exception is
+documented in DESIGN.md: `log10` (double, libm on the CPU vs ocml on the GPU) may round a
+feature differently with probability ~1e-9 per call; the tolerance fallback below (1e-4
+relative on gains, stated by north_star) is reported, never silently used.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, golden
+from oracle.binding import Oracle
+from rnnoise_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_GAIN_REL = 1e-4  # north_star tolerance, only consulted when bit-identity fails
+
+
+def crc_rows(a):
+    return np.array([zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xFFFFFFFF for r in a], np.uint32)
+
+
+def oracle_run(blob, pcm_TNF, collect_state=True):
+    """per-stream oracle over a (T, N, 480) batch"""
+    T, N, _ = pcm_TNF.shape
+    outs = dict(out=np.zeros_like(pcm_TNF), vad=np.zeros((T, N), np.float32), gains=np.zeros((T, N, 32), np.float32),
+                features=np.zeros((T, N, 65), np.float32), pitch=np.zeros((T, N), np.int32),
+                silence=np.zeros((T, N), np.int32), state=np.zeros((N, capi.STATE_FLOATS), np.float32))
+    for s in range(N):
+        o = Oracle(blob)
+        r = o.run(pcm_TNF[:, s])
+        for k in ("out", "vad", "gains", "features", "pitch", "silence"):
+            outs[k][:, s] = r[k]
+        outs["state"][s] = o.get_state()
+    return outs
+
+
+def gpu_run(batch, pcm_TNF, per_frame_debug=False):
+    T, N, _ = pcm_TNF.shape
+    if not per_frame_debug:
+        out, vad, gains = batch.process(pcm_TNF)
+        return dict(out=out, vad=vad, gains=gains)
+    res = dict(out=np.zeros_like(pcm_TNF), vad=np.zeros((T, N), np.float32), gains=np.zeros((T, N, 32), np.float32),
+               features=np.zeros((T, N, 65), np.float32), pitch=np.zeros((T, N), np.int32),
+               silence=np.zeros((T, N), np.int32))
+    for t in range(T):
+        o, v, g = batch.process(pcm_TNF[t:t + 1])
+        f, s, p = batch.debug_last()
+        res["out"][t], res["vad"][t], res["gains"][t] = o[0], v[0], g[0]
+        res["features"][t], res["silence"][t], res["pitch"][t] = f, s, p
+    return res
+
+
+@pytest.fixture(scope="module")
+def model(blob_default):
+    return capi.Model(blob_default)
+
+
+def test_device_present():
+    assert capi.lib().rnnoise_amd_device_count() >= 1
+
+
+def test_free_running_bit_exact_with_stage_taps(model, blob_default):
+    """4 streams x 60 frames incl. leading silence: every stage output identical to the oracle"""
+    streams = [3, 8, 77, 130]
+    T = 60
+    pcm = synth.batch_pcm(streams, T, lead_silence=6)
+    want = oracle_run(blob_default, pcm)
+    b = capi.Batch(model, len(streams))
+    got = gpu_run(b, pcm, per_frame_debug=True)
+    assert np.array_equal(got["silence"], want["silence"])
+    assert np.array_equal(got["pitch"], want["pitch"]), np.argwhere(got["pitch"] != want["pitch"])[:5]
+    assert_bits_equal(got["features"], want["features"], "features")
+    assert_bits_equal(got["gains"], want["gains"], "raw gains")
+    assert_bits_equal(got["vad"], want["vad"], "vad")
+    assert_bits_equal(got["out"], want["out"], "pcm")
+    for i in range(len(streams)):
+        assert_bits_equal(b.export_state(i), want["state"][i], f"state of stream {i}")
+    assert want["silence"][:6].all() and not want["silence"][8:].any()
+
+
+def test_detail_golden_from_reference(model):
+    """reference outputs recorded in the build container (tests/golden/make_golden.py)"""
+    g = golden("detail_default.npz")
+    pcm = np.stack([g["s3_pcm"], g["s77_pcm"]], axis=1).astype(np.float32)
+    b = capi.Batch(model, 2)
+    got = gpu_run(b, pcm, per_frame_debug=True)
+    for i, s in enumerate((3, 77)):
+        assert np.array_equal(got["pitch"][:, i], g[f"s{s}_pitch"])
+        assert np.array_equal(got["silence"][:, i], g[f"s{s}_silence"])
+        assert_bits_equal(got["features"][:, i], g[f"s{s}_features"], "features")
+        assert_bits_equal(got["gains"][:, i], g[f"s{s}_gains"], "gains")
+        assert_bits_equal(got["vad"][:, i], g[f"s{s}_vad"], "vad")
+        assert_bits_equal(got["out"][:, i], g[f"s{s}_out"], "pcm")
+        assert_bits_equal(b.export_state(i), g[f"s{s}_state"], "state")
+
+
+def test_digest_golden_400_frames(model):
+    g = golden("digest_default.npz")
+    streams = (0, 1, 159, 4095)
+    pcm = synth.batch_pcm(streams, 400, lead_silence=5)
+    b = capi.Batch(model, 4)
+    got = gpu_run(b, pcm)
+    for i, s in enumerate(streams):
+        assert synth.crc32(pcm[:, i].astype(np.int16)) == int(g[f"s{s}_pcm_crc"])
+        ok = np.array_equal(got["gains"][:, i].view(np.uint32), g[f"s{s}_gains"].view(np.uint32))
+        if not ok:  # report against the stated tolerance instead of hiding it
+            rel = np.abs(got["gains"][:, i] - g[f"s{s}_gains"]) / np.maximum(np.abs(g[f"s{s}_gains"]), 1e-9)
+            raise AssertionError(f"stream {s}: gains not bit-identical; max rel {rel.max():.3e} "
+                                 f"(north_star tolerance {TOL_GAIN_REL}), frames over: {(rel.max(1) > TOL_GAIN_REL).sum()}")
+        assert_bits_equal(got["vad"][:, i], g[f"s{s}_vad"], "vad")
+        assert np.array_equal(crc_rows(got["out"][:, i]), g[f"s{s}_out_crc"])
+        assert synth.crc32(b.export_state(i)) == int(g[f"s{s}_state_crc"])
+
+
+def test_edge_case_golden(model):
+    g = golden("edge_default.npz")
+    names = ["loud", "dc", "impulses", "gaps"]
+    pcm = np.stack([g[f"{n}_pcm"] for n in names], axis=1).astype(np.float32)
+    b = capi.Batch(model, 4)
+    got = gpu_run(b, pcm)
+    for i, n in enumerate(names):
+        assert_bits_equal(got["gains"][:, i], g[f"{n}_gains"], f"{n} gains")
+        assert_bits_equal(got["vad"][:, i], g[f"{n}_vad"], f"{n} vad")
+        assert np.array_equal(crc_rows(got["out"][:, i]), g[f"{n}_out_crc"]), n
+        assert synth.crc32(b.export_state(i)) == int(g[f"{n}_state_crc"]), n
+
+
+def test_sparser_model_golden(blob_little):
+    g = golden("digest_little.npz")
+    m = capi.Model(blob_little)
+    pcm = synth.batch_pcm((2, 31), 200, lead_silence=3)
+    b = capi.Batch(m, 2)
+    got = gpu_run(b, pcm)
+    for i, s in enumerate((2, 31)):
+        assert_bits_equal(got["gains"][:, i], g[f"s{s}_gains"], "gains")
+        assert_bits_equal(got["vad"][:, i], g[f"s{s}_vad"], "vad")
+        assert np.array_equal(crc_rows(got["out"][:, i]), g[f"s{s}_out_crc"])
+        assert synth.crc32(b.export_state(i)) == int(g[f"s{s}_state_crc"])
+    b.close()
+    m.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65])
+def test_multi_stream_invariance(model, blob_default, n):
+    """stream k of a batch of N equals the same stream run alone: no cross-talk"""
+    T = 12
+    pcm = synth.batch_pcm([s % 7 for s in range(n)], T)
+    b = capi.Batch(model, n)
+    out, vad, gains = b.process(pcm)
+    want = oracle_run(blob_default, pcm[:, :7] if n >= 7 else pcm)
+    for s in range(n):
+        r = s % 7 if n >= 7 else s
+        assert_bits_equal(out[:, s], want["out"][:, r], f"pcm stream {s}")
+        assert_bits_equal(gains[:, s], want["gains"][:, r], f"gains stream {s}")
+        assert_bits_equal(vad[:, s], want["vad"][:, r], f"vad stream {s}")
+
+
+def test_full_size_batch_properties(model, blob_default):
+    """BASELINE config 2 size (4096 streams): size-independent checks -- replicated streams stay
+    identical, and a sample of streams matches the oracle bit for bit."""
+    N, T = 4096, 6
+    base = synth.batch_pcm(range(16), T)
+    pcm = np.ascontiguousarray(np.tile(base, (1, N // 16, 1)))
+    b = capi.Batch(model, N)
+    out, vad, gains = b.process(pcm)
+    ref = out[:, :16]
+    assert all(np.array_equal(out[:, k:k + 16].view(np.uint32), ref.view(np.uint32)) for k in range(0, N, 16))
+    assert np.array_equal(gains.reshape(T, N // 16, 16, 32), np.broadcast_to(gains[:, None, :16], (T, N // 16, 16, 32)))
+    want = oracle_run(blob_default, base)
+    assert_bits_equal(out[:, :16], want["out"], "pcm")
+    assert_bits_equal(gains[:, :16], want["gains"], "gains")
+    assert_bits_equal(b.export_state(4095), want["state"][15], "state of the last stream")
+
+
+def test_state_export_import_round_trip_and_teacher_forcing(model, blob_default):
+    pcm = synth.batch_pcm([5, 6], 40)
+    b = capi.Batch(model, 2)
+    b.process(pcm[:25])
+    st = [b.export_state(0), b.export_state(1)]
+    b2 = capi.Batch(model, 2)
+    b2.import_state(0, st[1])  # swapped on purpose
+    b2.import_state(1, st[0])
+    o1, v1, g1 = b.process(pcm[25:])
+    o2, v2, g2 = b2.process(pcm[25:, ::-1])
+    assert_bits_equal(o1[:, 0], o2[:, 1], "pcm after import")
+    assert_bits_equal(g1[:, 1], g2[:, 0], "gains after import")
+    # an oracle state drives the GPU and vice versa
+    o = Oracle(blob_default)
+    o.run(pcm[:25, 0])
+    assert_bits_equal(o.get_state(), st[0], "oracle vs exported state")
+    bad = st[0].copy()
+    bad[0] += 1.0  # analysis_mem no longer equals the tail of pitch_buf
+    with pytest.raises(RuntimeError):
+        b2.import_state(0, bad)
+
+
+def test_reset_restores_initial_state(model):
+    pcm = synth.batch_pcm([1, 2, 3], 10)
+    b = capi.Batch(model, 3)
+    a = b.process(pcm)
+    b.reset()
+    c = b.process(pcm)
+    for x, y in zip(a, c):
+        assert_bits_equal(x, y, "after reset")
+    assert not a[0][0].any()  # first output frame is all zeros
+
+
+def test_drop_in_single_stream_api(model, blob_default):
+    """rnnoise_create / rnnoise_process_frame (in place, like examples/rnnoise_demo.c:57) / destroy"""
+    T = 30
+    pcm = synth.stream_pcm(42, T, lead_silence=3).astype(np.float32).reshape(T, 480)
+    want = Oracle(blob_default).run(pcm)
+    st1, st2 = capi.DenoiseState(model), capi.DenoiseState(model)
+    other = synth.stream_pcm(43, T).astype(np.float32).reshape(T, 480)
+    for t in range(T):
+        y, vad = st1.process_frame(pcm[t])
+        st2.process_frame(other[t])  # interleaved second state must not disturb the first
+        assert_bits_equal(y, want["out"][t], f"frame {t}")
+        assert np.float32(vad).view(np.uint32) == want["vad"][t].view(np.uint32)
+    # caller-allocated storage (rnnoise_get_size + rnnoise_init, rnnoise.h:57,71)
+    import ctypes as C
+    L = capi.lib()
+    buf = (C.c_char * L.rnnoise_get_size())()
+    assert L.rnnoise_init(C.cast(buf, C.c_void_p), model.h) == 0
+    x = pcm[0].copy()
+    L.rnnoise_process_frame(C.cast(buf, C.c_void_p), x.ctypes.data_as(C.POINTER(C.c_float)),
+                            x.ctypes.data_as(C.POINTER(C.c_float)))
+    assert not x.any()
+
+
+def test_device_resident_path_with_torch_stream(model, blob_default):
+    """rnnoise_batch_process_device on torch-owned HBM and torch's current stream"""
+    torch = pytest.importorskip("torch")
+    N, T = 8, 5
+    pcm = synth.batch_pcm(range(N), T)
+    want = oracle_run(blob_default, pcm)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(pcm).to(dev)
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty((T, N), device=dev)
+    d_g = torch.empty((T, N, 32), device=dev)
+    b = capi.Batch(model, N)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        b.process_device(d_out.data_ptr(), d_in.data_ptr(), d_vad.data_ptr(), d_g.data_ptr(), T,
+                         torch.cuda.current_stream().cuda_stream)
+    side.synchronize()
+    assert_bits_equal(d_out.cpu().numpy(), want["out"], "pcm")
+    assert_bits_equal(d_g.cpu().numpy(), want["gains"], "gains")
+    assert_bits_equal(d_vad.cpu().numpy(), want["vad"], "vad")
