@@ -53,4 +53,14 @@
 #define RN_OFF_DELAYED_EXP (RN_OFF_DELAYED_EP + 32)
 #define RN_STATE_FLOATS (RN_OFF_DELAYED_EXP + 32)           /* 6282 words = 25,128 B */
 
+/* Stage-tap record of the pitch analysis (tests only; rnnoise_batch_debug_pitch) */
+#define RN_DBG_XLP 0          /* [864] decimated + whitened signal (src/pitch.c:146-214)  */
+#define RN_DBG_AC 864         /* [5]   lag-windowed autocorrelation                       */
+#define RN_DBG_LPC 869        /* [5]   FIR taps lpc2[]                                    */
+#define RN_DBG_XC_COARSE 880  /* [147] coarse xcorr (src/pitch.c:332)                     */
+#define RN_DBG_BEST 1030      /* coarse best0,best1, fine best0,best1, offset, 768-pitch  */
+#define RN_DBG_XC_FINE 1040   /* [294] fine xcorr (src/pitch.c:344-361)                   */
+#define RN_DBG_DOTS 1340      /* xx, xy, yy, T, xcorr[3] of rnn_remove_doubling           */
+#define RN_DBG_FLOATS 1360
+
 #endif /* RN_LAYOUT_H */

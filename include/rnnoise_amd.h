@@ -67,6 +67,10 @@ RNNOISE_EXPORT long rnnoise_model_weight_bytes(RNNModel *model);
  * silence flags [N] and final pitch periods [N] (host buffers, any may be NULL). */
 RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch);
 
+/* Pitch-analysis stage taps ([N][RN_DBG_FLOATS], layout rn_layout.h RN_DBG_*).  The first
+ * call arms the taps (dst may be NULL); later calls copy the last step's record. Tests only. */
+RNNOISE_EXPORT int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst);
+
 /* Average device time per launch of each kernel over the calls since the last query, in
  * milliseconds, measured with HIP events on the launch stream when timing is enabled.
  * ms[0]=analysis, ms[1]=network, ms[2]=synthesis. */

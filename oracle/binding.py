@@ -90,6 +90,8 @@ class Oracle(_FrameRunner):
             L.rno_tables.argtypes = [C.POINTER(C.c_float)] * 3 + [C.POINTER(C.c_int)]
             L.rno_pitch.restype = C.c_float
             L.rno_pitch.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+            L.rno_pitch_debug.restype = C.c_float
+            L.rno_pitch_debug.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float)]
             L.rno_compute_rnn.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
             L.rno_band_energy.argtypes = [C.POINTER(C.c_float)] * 2
             L.rno_interp_band_gain.argtypes = [C.POINTER(C.c_float)] * 2
@@ -154,6 +156,15 @@ class Oracle(_FrameRunner):
         lp = np.zeros(864, np.float32)
         g = cls.lib().rno_pitch(_fp(buf), last_period, last_gain, C.byref(T), _fp(lp))
         return T.value, g, lp
+
+
+    @classmethod
+    def pitch_debug(cls, buf1728: np.ndarray, last_period: int, last_gain: float):
+        buf = np.ascontiguousarray(buf1728, np.float32)
+        T = C.c_int(0)
+        dbg = np.zeros(1360, np.float32)
+        g = cls.lib().rno_pitch_debug(_fp(buf), last_period, last_gain, C.byref(T), _fp(dbg))
+        return T.value, g, dbg
 
 
 class RefHarness(_FrameRunner):

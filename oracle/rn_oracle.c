@@ -292,6 +292,10 @@ static void dct(float *out, const float *in) {
  * MAC16_16(c,a,b) = c + a*b unfused, HALF32(x) = .5f*x).
  * Every dot product is one serial chain over the sample index (pitch.h:51-142).
  * ---------------------------------------------------------------------------------------- */
+/* optional stage taps for tests (layout: include/rn_layout.h RN_DBG_*) */
+static float *g_dbg;
+#define DBG(off, val) do { if (g_dbg) g_dbg[(off)] = (float)(val); } while (0)
+
 static float inner_prod(const float *x, const float *y, int n) {
   float s = 0;
   int i;
@@ -347,6 +351,7 @@ static void pitch_downsample(const float *x, float *x_lp) {
   lpc2[2] = lpc[2] + c1 * lpc[1];
   lpc2[3] = lpc[3] + c1 * lpc[2];
   lpc2[4] = c1 * lpc[3];
+  for (i = 0; i < 5; i++) { DBG(RN_DBG_AC + i, ac[i]); DBG(RN_DBG_LPC + i, lpc2[i]); }
   { /* celt_fir5, in place, zero initial memory */
     float m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
     for (i = 0; i < n; i++) {
@@ -407,6 +412,8 @@ static int pitch_search(const float *x_lp, const float *y) {
   for (j = 0; j < (LEN + MAXP) >> 2; j++) y4[j] = y[2 * j];
   for (i = 0; i < MAXP >> 2; i++) xcorr[i] = inner_prod(x4, y4 + i, LEN >> 2);
   find_best_pitch(xcorr, y4, LEN >> 2, MAXP >> 2, best);
+  for (i = 0; i < MAXP >> 2; i++) DBG(RN_DBG_XC_COARSE + i, xcorr[i]);
+  DBG(RN_DBG_BEST + 0, best[0]); DBG(RN_DBG_BEST + 1, best[1]);
   for (i = 0; i < MAXP >> 1; i++) {
     float sum;
     xcorr[i] = 0;
@@ -415,6 +422,8 @@ static int pitch_search(const float *x_lp, const float *y) {
     xcorr[i] = (-1 > sum) ? -1 : sum;
   }
   find_best_pitch(xcorr, y, LEN >> 1, MAXP >> 1, best);
+  for (i = 0; i < MAXP >> 1; i++) DBG(RN_DBG_XC_FINE + i, xcorr[i]);
+  DBG(RN_DBG_BEST + 2, best[0]); DBG(RN_DBG_BEST + 3, best[1]);
   if (best[0] > 0 && best[0] < (MAXP >> 1) - 1) {
     float a = xcorr[best[0] - 1], b = xcorr[best[0]], c = xcorr[best[0] + 1];
     if ((c - a) > .7f * (b - a)) offset = 1;
@@ -423,6 +432,7 @@ static int pitch_search(const float *x_lp, const float *y) {
   } else {
     offset = 0;
   }
+  DBG(RN_DBG_BEST + 4, offset);
   return 2 * best[0] - offset;
 }
 
@@ -454,6 +464,7 @@ static float remove_doubling(const float *xbuf, int *T0_, int prev_period, float
     yy_lookup[i] = (0 > yy) ? 0 : yy;
   }
   yy = yy_lookup[T0];
+  DBG(RN_DBG_DOTS + 0, xx); DBG(RN_DBG_DOTS + 1, xy); DBG(RN_DBG_DOTS + 2, yy);
   best_xy = xy;
   best_yy = yy;
   g = g0 = pitch_gain(xy, xx, yy);
@@ -497,6 +508,7 @@ static float remove_doubling(const float *xbuf, int *T0_, int prev_period, float
   else if ((xc[0] - xc[2]) > .7f * (xc[1] - xc[2])) offset = -1;
   else offset = 0;
   if (pg > g) pg = g;
+  DBG(RN_DBG_DOTS + 3, T); DBG(RN_DBG_DOTS + 4, xc[0]); DBG(RN_DBG_DOTS + 5, xc[1]); DBG(RN_DBG_DOTS + 6, xc[2]);
   *T0_ = 2 * T + offset;
   if (*T0_ < minperiod0) *T0_ = minperiod0;
   return pg;
@@ -509,12 +521,24 @@ float rno_pitch(const float *pitch_buf, int last_period, float last_gain, int *p
   float gain;
   tables_init();
   pitch_downsample(pitch_buf, lp);
+  if (g_dbg) memcpy(g_dbg + RN_DBG_XLP, lp, sizeof lp);
   pitch_index = pitch_search(lp + (RN_PITCH_MAX_PERIOD >> 1), lp);
   pitch_index = RN_PITCH_MAX_PERIOD - pitch_index;
+  DBG(RN_DBG_BEST + 5, pitch_index);
   gain = remove_doubling(lp, &pitch_index, last_period, last_gain);
   if (x_lp_out) memcpy(x_lp_out, lp, sizeof lp);
   *pitch_index_out = pitch_index;
   return gain;
+}
+
+/* same as rno_pitch, additionally filling the RN_DBG_FLOATS stage-tap record */
+float rno_pitch_debug(const float *pitch_buf, int last_period, float last_gain, int *pitch_index_out, float *dbg) {
+  float r;
+  memset(dbg, 0, RN_DBG_FLOATS * sizeof(float));
+  g_dbg = dbg;
+  r = rno_pitch(pitch_buf, last_period, last_gain, pitch_index_out, NULL);
+  g_dbg = NULL;
+  return r;
 }
 
 /* ------------------------------------------------------------------------------------------

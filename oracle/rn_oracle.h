@@ -43,6 +43,7 @@ float rno_process_frame(const RnoModel *m, float *state, float *out, const float
 void rno_fft(const float *in_ri, float *out_ri); /* 960 interleaved complex */
 void rno_tables(float *half_window480, float *dct1024, float *twiddles1920, int *bitrev960);
 float rno_pitch(const float *pitch_buf1728, int last_period, float last_gain, int *pitch_index_out, float *x_lp864);
+float rno_pitch_debug(const float *pitch_buf1728, int last_period, float last_gain, int *pitch_index_out, float *dbg);
 void rno_compute_rnn(const RnoModel *m, float *state, float *gains, float *vad, const float *features);
 void rno_band_energy(float *bandE, const float *X_ri);
 void rno_interp_band_gain(float *g481, const float *bandE);

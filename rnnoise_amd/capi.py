@@ -31,13 +31,28 @@ EXPORTS = [
     "rnnoise_batch_reset", "rnnoise_batch_process", "rnnoise_batch_process_device",
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
-    "rnnoise_batch_kernel_ms",
+    "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
 ]
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's).  If our library were loaded first it would pull
+    in the system runtime and a later `import torch` would bring a second one: streams and
+    events could then not be shared.  Pre-loading the runtime torch will use makes our
+    DT_NEEDED entry resolve to it, whichever import order the application picks."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
 def lib():
     global _lib
     if _lib is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -71,6 +86,7 @@ def lib():
         L.rnnoise_model_weight_bytes.restype = C.c_long
         L.rnnoise_model_weight_bytes.argtypes = [vp]
         L.rnnoise_batch_debug_last.argtypes = [vp, fp, ip, ip]
+        L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         _lib = L
@@ -171,6 +187,15 @@ class Batch:
         if lib().rnnoise_batch_debug_last(self.h, _fp(f), s.ctypes.data_as(ip), p.ctypes.data_as(ip)):
             raise RuntimeError("debug_last failed")
         return f, s, p
+
+    def debug_pitch(self, arm_only: bool = False):
+        if arm_only:
+            lib().rnnoise_batch_debug_pitch(self.h, None)
+            return None
+        d = np.empty((self.n, 1360), np.float32)
+        if lib().rnnoise_batch_debug_pitch(self.h, _fp(d)):
+            raise RuntimeError("debug_pitch failed")
+        return d
 
     def enable_timing(self, on: bool = True):
         lib().rnnoise_batch_enable_timing(self.h, int(on))

@@ -218,7 +218,7 @@ struct AnalysisLds {
   float xlp[864];               // 2x decimated, LPC-whitened (src/pitch.c:146-214)
   cpx F[RN_WINDOW_SIZE];        // FFT work area; also yy_lookup scratch
   cpx X[RN_FREQ_SIZE + 1];      // spectrum of the current frame, kept for the X.P correlation
-  float y4[388];                // 4x decimated (src/pitch.c:309-312)
+  float y4[432];                // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
   float xc[296];                // xcorr[] of pitch_search
   float sums[40];               // band accumulators (34 used)
   float Ex[RN_NB_BANDS], Ep[RN_NB_BANDS], Exp[RN_NB_BANDS], Ly[RN_NB_BANDS];
@@ -235,6 +235,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   const int s = blockIdx.x, lane = threadIdx.x;
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
   float *Ex = L.Ex, *Ep = L.Ep, *Exp = L.Exp, *Ly = L.Ly, *sums = L.sums;
+  float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
 
   // ---- load: shifted pitch buffer + raw input ----
   const float *pb_old = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
@@ -351,6 +352,10 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     lpc2[2] = lpc[2] + c1 * lpc[1];
     lpc2[3] = lpc[3] + c1 * lpc[2];
     lpc2[4] = c1 * lpc[3];
+    if (dbg && lane < 5) {
+      dbg[RN_DBG_AC + lane] = ac[lane];
+      dbg[RN_DBG_LPC + lane] = lpc2[lane];
+    }
   }
   {  // celt_fir5 in place (src/pitch.c:104-143): outputs are independent given the OLD samples
     float r[14];
@@ -377,13 +382,18 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   }
   __syncthreads();
 
+  if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = L.xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
-  for (int j = lane; j < 387; j += WAVE) L.y4[j] = L.xlp[2 * j];
+  for (int j = lane; j < 432; j += WAVE) L.y4[j] = L.xlp[2 * j];
   __syncthreads();
   for (int lag = lane; lag < 147; lag += WAVE) L.xc[lag] = chain_dot(L.y4 + 192, L.y4 + lag, 240);
   __syncthreads();
   int bp0, bp1;
   find_best_pitch(L.xc, L.y4, 240, 147, bp0, bp1);
+  if (dbg) {
+    for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = L.xc[i];
+    if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
+  }
   __syncthreads();
   for (int i = lane; i < 294; i += WAVE) L.xc[i] = 0;
   __syncthreads();
@@ -403,6 +413,10 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     else if ((a - c) > .7f * (b - c)) offset = -1;
   }
   int pitch_index = RN_PITCH_MAX_PERIOD - (2 * bp0 - offset);
+  if (dbg) {
+    for (int i = lane; i < 294; i += WAVE) dbg[RN_DBG_XC_FINE + i] = L.xc[i];
+    if (lane == 0) { dbg[RN_DBG_BEST + 2] = bp0; dbg[RN_DBG_BEST + 3] = bp1; dbg[RN_DBG_BEST + 4] = offset; dbg[RN_DBG_BEST + 5] = pitch_index; }
+  }
 
   // ---- rnn_remove_doubling (src/pitch.c:423-528): maxperiod 384, minperiod 30, N 480 ----
   float pgain;
@@ -445,6 +459,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     __syncthreads();
     float yy = yyl[T0];
     float best_xy = xy, best_yy = yy;
+    if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
     const float g0 = pitch_gain(xy, xx, yy);
     float gg = g0;
     for (int k = 2; k <= 15; k++) {
@@ -480,6 +495,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     if (lane < 3) dots[lane] = chain_dot(x, x - (T + lane - 1), N);
     __syncthreads();
     float xc0 = dots[0], xc1 = dots[1], xc2 = dots[2];
+    if (dbg && lane == 0) { dbg[RN_DBG_DOTS + 3] = T; dbg[RN_DBG_DOTS + 4] = xc0; dbg[RN_DBG_DOTS + 5] = xc1; dbg[RN_DBG_DOTS + 6] = xc2; }
     int off2 = 0;
     if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;
     else if ((xc0 - xc2) > .7f * (xc1 - xc2)) off2 = -1;

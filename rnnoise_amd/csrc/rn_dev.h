@@ -65,4 +65,5 @@ struct RnGroupDev {
   int *pitch;          // [N]   final period (debug/tests)
   float *gains;        // [N][32] raw network gains of the current step
   float *vad;          // [N]
+  float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };

@@ -343,6 +343,7 @@ struct RNNoiseBatch {
   RnModelDev m{};
   RnTablesDev tb{};
   float *scratch_gains = nullptr, *scratch_vad = nullptr;
+  float *debug_buf = nullptr;
   // host-buffer staging
   float *stage_in = nullptr, *stage_out = nullptr, *stage_vad = nullptr, *stage_gains = nullptr;
   int stage_frames = 0;
@@ -530,6 +531,7 @@ extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (b->stage_vad) hipFree(b->stage_vad);
   if (b->stage_gains) hipFree(b->stage_gains);
   if (b->arena) hipFree(b->arena);
+  if (b->debug_buf) hipFree(b->debug_buf);
   delete b;
 }
 
@@ -679,6 +681,20 @@ extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *s
   }
   if (silence) D2H(silence, b->g.silence, b->n);
   if (pitch) D2H(pitch, b->g.pitch, b->n);
+  return 0;
+}
+
+// pitch stage taps of the last step ([N][RN_DBG_FLOATS]); the first call (dst==NULL) arms them
+extern "C" int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst) {
+  if (!b) return -1;
+  HIP_OK(hipSetDevice(b->device));
+  HIP_OK(hipDeviceSynchronize());
+  if (!b->debug_buf) {
+    HIP_OK(hipMalloc((void **)&b->debug_buf, (size_t)b->n * RN_DBG_FLOATS * 4));
+    HIP_OK(hipMemset(b->debug_buf, 0, (size_t)b->n * RN_DBG_FLOATS * 4));
+    b->g.debug = b->debug_buf;
+  }
+  if (dst) D2H(dst, b->debug_buf, (size_t)b->n * RN_DBG_FLOATS);
   return 0;
 }
 

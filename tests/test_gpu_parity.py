@@ -65,6 +65,35 @@ def test_device_present():
     assert capi.lib().rnnoise_amd_device_count() >= 1
 
 
+SECTIONS = [("xlp", 0, 864), ("ac", 864, 869), ("lpc2", 869, 874), ("xcorr_coarse", 880, 1027), ("best", 1030, 1036),
+            ("xcorr_fine", 1040, 1334), ("doubling", 1340, 1347)]
+
+
+def test_pitch_stage_taps(model, blob_default):
+    """teacher-forced pitch analysis: every intermediate of rnn_pitch_downsample / rnn_pitch_search /
+    rnn_remove_doubling against the oracle, fed with the GPU's own pitch buffer"""
+    streams = [3, 8]
+    T = 14
+    pcm = synth.batch_pcm(streams, T, lead_silence=2)
+    b = capi.Batch(model, len(streams))
+    b.debug_pitch(arm_only=True)
+    orc = [Oracle(blob_default) for _ in streams]
+    prev = [(0, 0.0)] * len(streams)
+    for t in range(T):
+        b.process(pcm[t:t + 1])
+        taps = b.debug_pitch()
+        for i in range(len(streams)):
+            orc[i].process(pcm[t, i])
+            st = b.export_state(i)
+            ost = orc[i].get_state()
+            assert_bits_equal(st[960:960 + 1728], ost[960:960 + 1728], f"frame {t} pitch_buf (biquad)")
+            Tp, gain, want = Oracle.pitch_debug(st[960:960 + 1728], prev[i][0], prev[i][1])
+            for name, a0, a1 in SECTIONS:
+                assert_bits_equal(taps[i, a0:a1], want[a0:a1], f"frame {t} stream {i} {name}")
+            assert int(st[960 + 1728 + 1:960 + 1728 + 2].view(np.int32)[0]) == Tp
+            prev[i] = (Tp, gain)
+
+
 def test_free_running_bit_exact_with_stage_taps(model, blob_default):
     """4 streams x 60 frames incl. leading silence: every stage output identical to the oracle"""
     streams = [3, 8, 77, 130]
