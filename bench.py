@@ -184,13 +184,8 @@ def main():
     kms = batch.kernel_ms()
     batch.enable_timing(False)
 
-    frames = float(N * K)
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ff = torch.tensor([frames], device=dev, dtype=torch.float64)
-        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
-        dt, frames = float(tt.item()), float(ff.item())
+    from rnnoise_amd.dist import aggregate_throughput
+    frames, dt = aggregate_throughput(float(N * K), dt, dist, dev)
     value = frames / dt
 
     if rank == 0:
