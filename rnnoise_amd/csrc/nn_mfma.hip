@@ -1,9 +1,258 @@
-// nn_mfma.hip -- batched MFMA network path (placeholder until the vector path is validated on
-// hardware; rnnoise_batch_set_nn_path(b, 1) is refused while this returns NotSupported).
+// nn_mfma.hip -- K2, batched MFMA path: the network (src/rnn.c:44-60) recast as
+// (16 streams x K) . (K x outputs) matrix products, one workgroup (4 waves) per tile of 16
+// streams.
+//
+//   int8 layers (conv2, 6 GRU matrices): v_mfma_i32_16x16x64_i8 on the block-sparse weights
+//     zero-filled to dense and pre-swizzled into A-fragment order (shim.cpp: stage_mfma), the
+//     activations quantised exactly like the x86 path (u8, src/vec_avx.h:326-341) and
+//     re-centred to s8 = u8-128; acc_x86 = acc_mfma + 128*rowsum(w).  Integer => exact.
+//   float layers (conv1, dense_out): v_mfma_f32_16x16x4_f32, which on gfx950 is bitwise a
+//     k-ordered fmaf chain (tools/mfma_probe.hip, cdna_hip_programming.md section 3) = the AVX2
+//     sgemv order (src/vec_avx.h:672-730).  vad_dense is the unfused scalar tail
+//     (vec_avx.h:732-736) and stays on the VALU, lane = stream.
+//
+// Fragment maps (verified on hardware by the probe): A lane l -> row l&15, k-group l>>4;
+// B lane l -> column (stream) l&15, k-group l>>4; C/D lane l, reg r -> row 4*(l>>4)+r, col l&15.
+// Results are bit-identical to the vector path and to the oracle.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "rn_dev.h"
 
-extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t) {
-  return hipErrorNotSupported;
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define TS 16          // streams per workgroup
+#define NTHREADS 256   // 4 waves
+#define KT 6           // 384 / 64 k-tiles of every int8 layer
+
+// ---- x86-profile activations (same arithmetic as nn_kernels.hip; LUT staged in LDS) ----
+__device__ __forceinline__ float rcp_x86(float x, const uint32_t *lut) {
+  uint32_t b = __float_as_uint(x);
+  return __uint_as_float(lut[(b >> 12) & 0x7ff] - ((b & 0x7f800000u) - 0x3f800000u));
 }
-extern "C" int rn_nn_mfma_available(void) { return 0; }
+__device__ __forceinline__ float tanh_x86(float x, const uint32_t *lut) {  // src/vec_avx.h:398-416
+  const float N0 = 952.52801514f, N1 = 96.39235687f, N2 = 0.60863042f;
+  const float D0 = 952.72399902f, D1 = 413.36801147f, D2 = 11.88600922f;
+  float x2 = x * x;
+  float num = fmaf(fmaf(N2, x2, N1), x2, N0);
+  float den = fmaf(fmaf(D2, x2, D1), x2, D0);
+  num = num * x;
+  num = num * rcp_x86(den, lut);
+  num = (1.f < num) ? 1.f : num;
+  return (-1.f > num) ? -1.f : num;
+}
+__device__ __forceinline__ float sigmoid_x86(float x, const uint32_t *lut) {  // src/vec_avx.h:426-445
+  const float N0 = 238.13200378f, N1 = 6.02452230f, N2 = 0.00950985f;
+  const float D0 = 952.72399902f, D1 = 103.34200287f, D2 = 0.74287558f;
+  float x2 = x * x;
+  float num = fmaf(fmaf(N2, x2, N1), x2, N0);
+  float den = fmaf(fmaf(D2, x2, D1), x2, D0);
+  num = num * x;
+  num = fmaf(num, rcp_x86(den, lut), .5f);
+  num = (1.f < num) ? 1.f : num;
+  return (0.f > num) ? 0.f : num;
+}
+__device__ __forceinline__ int quant_s8(float x) {  // src/vec_avx.h:326-341, then -128
+  float xf = fmaf(x, 127.f, 127.f);
+  int xi = (xf >= -2147483648.f && xf < 2147483648.f) ? (int)rintf(xf) : INT32_MIN;
+  int u16 = xi < 0 ? 0 : (xi > 65535 ? 65535 : xi);
+  int s16 = (int)(int16_t)(uint16_t)u16;
+  int u8 = s16 < 0 ? 0 : (s16 > 255 ? 255 : s16);
+  return u8 - 128;
+}
+__device__ __forceinline__ int pack4(float a, float b, float c, float d) {
+  return (quant_s8(a) & 0xff) | ((quant_s8(b) & 0xff) << 8) | ((quant_s8(c) & 0xff) << 16) | ((quant_s8(d) & 0xff) << 24);
+}
+
+// byte offset of activation (stream n, input k) inside a B-fragment-ordered buffer:
+// [k/64][lane = n + 16*((k%64)/16)][k%16]
+__device__ __forceinline__ int frag_off(int n, int k) { return (((k >> 6) * 64 + n + 16 * ((k >> 4) & 3)) << 4) + (k & 15); }
+
+struct MfmaLds {
+  uint32_t lut[2048];             // rcpps table
+  float tmp1[TS][197];            // conv1 input [t-2|t-1|t], padded row
+  int8_t xq[2][KT * 64 * 16];     // quantised layer input, B-fragment order (double buffer)
+  int8_t hq[KT * 64 * 16];        // quantised recurrent state
+};
+
+// one int8 output-row tile: 6 MFMAs over K=384, A straight from the pre-swizzled weights
+__device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt, int lane, const v4i *bfrag) {
+  v4i acc = {0, 0, 0, 0};
+  const v4i *a = reinterpret_cast<const v4i *>(wmf) + (size_t)rt * KT * 64 + lane;
+#pragma unroll
+  for (int kt = 0; kt < KT; kt++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[kt * 64], bfrag[kt], acc, 0, 0, 0);
+  return acc;
+}
+
+// float(acc_x86)*scale + subias for the 4 rows a lane owns (src/nnet_arch.h:145-151)
+__device__ __forceinline__ v4f int8_finish(const RnLinearDev &l, int row0, v4i acc) {
+  const v4i rs = *reinterpret_cast<const v4i *>(l.rowsum128 + row0);
+  const v4f sc = *reinterpret_cast<const v4f *>(l.scale + row0);
+  const v4f sb = *reinterpret_cast<const v4f *>(l.bias + row0);
+  v4f o;
+#pragma unroll
+  for (int r = 0; r < 4; r++) o[r] = (float)(acc[r] + rs[r]) * sc[r] + sb[r];
+  return o;
+}
+
+extern "C" __global__ void __launch_bounds__(NTHREADS)
+rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
+  __shared__ __attribute__((aligned(16))) MfmaLds L;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+  const int N = g.n_streams, s0 = blockIdx.x * TS;
+  const int sn = (s0 + n < N) ? s0 + n : N - 1;              // this lane's stream (clamped for loads)
+  const bool live = (s0 + n < N) && !g.silence[sn];          // silent streams keep state (src/denoise.c:474)
+  const uint32_t *lut = L.lut;
+
+  for (int i = tid; i < 2048; i += NTHREADS) L.lut[i] = tb.rcp_lut[i];
+  // ---- conv1 input: [conv1_state(130) | features(65) | 0] per stream ----
+  for (int e = tid; e < TS * 196; e += NTHREADS) {
+    const int q = e / 196, k = e - q * 196, s = (s0 + q < N) ? s0 + q : N - 1;
+    float v = 0;
+    if (k < 130) v = g.conv1_state[(size_t)s * 130 + k];
+    else if (k < 195) v = g.features[(size_t)s * 68 + (k - 130)];
+    L.tmp1[q][k] = v;
+  }
+  // conv2 history: quantise old[0..255] into xq[0] (k = 0..255); keep old[128..255] to shift the state
+  v4f hist[4];
+  int hq_[4], hk_[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int chunk = tid + c * NTHREADS, q = chunk >> 6, k = (chunk & 63) << 2;  // 16 streams x 64 chunks of 4
+    const int s = (s0 + q < N) ? s0 + q : N - 1;
+    hist[c] = *reinterpret_cast<const v4f *>(g.conv2_state + (size_t)s * 256 + k);
+    hq_[c] = q;
+    hk_[c] = k;
+    *reinterpret_cast<int *>(L.xq[0] + frag_off(q, k)) = pack4(hist[c][0], hist[c][1], hist[c][2], hist[c][3]);
+  }
+  __syncthreads();
+  // state shifts (src/nnet.c:122): conv1 history <- tmp1[65..194]; conv2 history[0..127] <- old[128..255]
+  for (int e = tid; e < TS * 130; e += NTHREADS) {
+    const int q = e / 130, k = e - q * 130;
+    if (s0 + q < N && !g.silence[s0 + q]) g.conv1_state[(size_t)(s0 + q) * 130 + k] = L.tmp1[q][65 + k];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+    if (hk_[c] >= 128 && s0 + hq_[c] < N && !g.silence[s0 + hq_[c]])
+      *reinterpret_cast<v4f *>(g.conv2_state + (size_t)(s0 + hq_[c]) * 256 + hk_[c] - 128) = hist[c];
+
+  // ---- conv1: f32 MFMA, 195(+1) -> 128; wave w owns output rows 32w .. 32w+31 ----
+  {
+    v4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const float *fw = m.conv1.fw + 32 * wave + n;
+    for (int j = 0; j < 49; j++) {
+      const int k = 4 * j + gq;
+      const float b = L.tmp1[n][k];
+      const float a0 = (k < RN_CONV1_K) ? fw[k * 128] : 0.f, a1 = (k < RN_CONV1_K) ? fw[k * 128 + 16] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int row0 = 32 * wave + 16 * h + 4 * gq;
+      const v4f a = h ? acc1 : acc0, bs = *reinterpret_cast<const v4f *>(m.conv1.bias + row0);
+      v4f c1;
+#pragma unroll
+      for (int r = 0; r < 4; r++) c1[r] = tanh_x86(a[r] + bs[r], lut);
+      *reinterpret_cast<int *>(L.xq[0] + frag_off(n, 256 + row0)) = pack4(c1[0], c1[1], c1[2], c1[3]);
+      if (live) *reinterpret_cast<v4f *>(g.conv2_state + (size_t)sn * 256 + 128 + row0) = c1;
+    }
+  }
+  __syncthreads();
+
+  // ---- conv2: int8 dense 384 -> 384, tanh; wave w owns row tiles w, w+4, ... ----
+  {
+    v4i bx[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) bx[kt] = *reinterpret_cast<const v4i *>(L.xq[0] + ((kt * 64 + lane) << 4));
+    for (int rt = wave; rt < 24; rt += 4) {
+      const int row0 = 16 * rt + 4 * gq;
+      v4f o = int8_finish(m.conv2, row0, int8_tile(m.conv2.wmf, rt, lane, bx));
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] = tanh_x86(o[r], lut);
+      if (s0 + n < N) *reinterpret_cast<v4f *>(g.nn_act + (size_t)sn * RN_GRU + row0) = o;  // f32 copy for dense_out
+      *reinterpret_cast<int *>(L.xq[1] + frag_off(n, row0)) = pack4(o[0], o[1], o[2], o[3]);
+    }
+  }
+
+  // ---- three GRUs (src/nnet.c:65-94); wave w owns hidden-unit tiles w, w+4, ... ----
+  int cur = 1;
+  for (int k = 0; k < 3; k++) {
+    float *st = g.gru_state + (size_t)k * N * RN_GRU;
+    for (int e = tid; e < TS * 96; e += NTHREADS) {  // quantise the old state into hq
+      const int q = e / 96, c4 = (e - q * 96) << 2, s = (s0 + q < N) ? s0 + q : N - 1;
+      const v4f h = *reinterpret_cast<const v4f *>(st + (size_t)s * RN_GRU + c4);
+      *reinterpret_cast<int *>(L.hq + frag_off(q, c4)) = pack4(h[0], h[1], h[2], h[3]);
+    }
+    __syncthreads();
+    const RnLinearDev &wi = m.gru_in[k], &wr = m.gru_rec[k];
+    v4i bx[KT], bh[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+      bx[kt] = *reinterpret_cast<const v4i *>(L.xq[cur] + ((kt * 64 + lane) << 4));
+      bh[kt] = *reinterpret_cast<const v4i *>(L.hq + ((kt * 64 + lane) << 4));
+    }
+    for (int u = wave; u < 24; u += 4) {
+      const int unit0 = 16 * u + 4 * gq;
+      const v4f h_old = *reinterpret_cast<const v4f *>(st + (size_t)sn * RN_GRU + unit0);
+      v4f gi[3], gr[3];
+#pragma unroll
+      for (int gate = 0; gate < 3; gate++) {
+        gi[gate] = int8_finish(wi, gate * RN_GRU + unit0, int8_tile(wi.wmf, gate * 24 + u, lane, bx));
+        gr[gate] = int8_finish(wr, gate * RN_GRU + unit0, int8_tile(wr.wmf, gate * 24 + u, lane, bh));
+        const v4f dg = *reinterpret_cast<const v4f *>(wr.diag + gate * RN_GRU + unit0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) gr[gate][r] += dg[r] * h_old[r];  // src/nnet_arch.h:153-161
+      }
+      v4f hn;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float z = sigmoid_x86(gi[0][r] + gr[0][r], lut);
+        const float rg = sigmoid_x86(gi[1][r] + gr[1][r], lut);
+        const float hh = tanh_x86(gi[2][r] + gr[2][r] * rg, lut);
+        hn[r] = z * h_old[r] + (1 - z) * hh;
+      }
+      if (live) *reinterpret_cast<v4f *>(st + (size_t)sn * RN_GRU + unit0) = hn;
+      *reinterpret_cast<int *>(L.xq[cur ^ 1] + frag_off(n, unit0)) = pack4(hn[0], hn[1], hn[2], hn[3]);
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+
+  // ---- dense_out (1536 -> 32, f32 MFMA chains, waves 0-1) and vad_dense (wave 2, lane = stream) ----
+  // cat = [conv2 out | gru1 | gru2 | gru3] (src/rnn.c:53-55); silent streams are computed on
+  // their unchanged state and discarded.
+  if (wave < 2) {
+    v4f acc = {0, 0, 0, 0};
+    const float *fw = m.dense_out.fw + 16 * wave + n;
+    for (int seg = 0; seg < 4; seg++) {
+      const float *src = (seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) + (size_t)sn * RN_GRU;
+      const float *fws = fw + (size_t)seg * RN_GRU * RN_NB_BANDS;
+      for (int j = 0; j < 96; j++) {
+        const int k = 4 * j + gq;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fws[k * RN_NB_BANDS], src[k], acc, 0, 0, 0);
+      }
+    }
+    const int row0 = 16 * wave + 4 * gq;
+    const v4f bs = *reinterpret_cast<const v4f *>(m.dense_out.bias + row0);
+    v4f o;
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[r] = live ? sigmoid_x86(acc[r] + bs[r], lut) : 0.f;
+    if (s0 + n < N) *reinterpret_cast<v4f *>(g.gains + (size_t)sn * RN_NB_BANDS + row0) = o;
+  } else if (wave == 2 && lane < TS) {
+    float acc = 0;
+    for (int seg = 0; seg < 4; seg++) {
+      const float *src = (seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) + (size_t)sn * RN_GRU;
+      const float *w = m.vad_dense.fw + seg * RN_GRU;
+      for (int j = 0; j < RN_GRU; j++) acc = acc + w[j] * src[j];  // unfused, src/vec_avx.h:732-736
+    }
+    if (s0 + n < N) g.vad[sn] = live ? sigmoid_x86(acc + m.vad_dense.bias[0], lut) : 0.f;
+  }
+}
+
+extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st) {
+  if (!m->conv2.wmf || !g->nn_act) return hipErrorNotSupported;
+  hipLaunchKernelGGL(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, *g, *m, *tb);
+  return hipGetLastError();
+}
+extern "C" int rn_nn_mfma_available(void) { return 1; }

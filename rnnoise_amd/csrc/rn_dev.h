@@ -34,6 +34,8 @@ struct RnLinearDev {
   const float *scale;     // per-output scale (already /127, c_export/common.py:248)
   const float *diag;      // recurrent diagonal [3*M] or null
   const int8_t *w;        // int8 blocks, 32 bytes each = [8 rows][4 cols]
+  const int8_t *wmf;      // same weights zero-filled to dense, in MFMA A-fragment order
+                          //   [row tile][k tile][lane][16 B]: row = 16*rt + (lane&15), k = 64*kt + 16*(lane>>4) + byte
   const int *rowsum128;   // 128 * sum_j w[i][j]  (offset that turns s8 x s8 dots into s8 x u8)
   const int *grp_start;   // [nout/8 + 1] first block of each 8-row group
   const uint16_t *cols;   // [nblocks] first input column of each block
@@ -65,5 +67,6 @@ struct RnGroupDev {
   int *pitch;          // [N]   final period (debug/tests)
   float *gains;        // [N][32] raw network gains of the current step
   float *vad;          // [N]
+  float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };

@@ -22,6 +22,7 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
+extern "C" int rn_nn_mfma_available(void);
 
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
@@ -178,7 +179,7 @@ struct Staging {
 };
 
 struct DevLinearOffsets {
-  size_t bias = 0, fw = 0, scale = 0, diag = 0, w = 0, rowsum = 0, grp = 0, cols = 0;
+  size_t bias = 0, fw = 0, scale = 0, diag = 0, w = 0, wmf = 0, rowsum = 0, grp = 0, cols = 0;
   bool has_fw = false, has_diag = false, has_cols = false, is_int8 = false;
 };
 
@@ -211,6 +212,22 @@ DevLinearOffsets stage_linear(Staging &st, const HostLinear &l) {
   }
   for (auto &v : rowsum) v *= 128;
   o.rowsum = st.add(rowsum.data(), 4 * rowsum.size());
+  {  // MFMA copy: zero-fill to dense [nout][nin], then A-fragment order (nn_mfma.hip)
+    std::vector<int8_t> dense((size_t)l.nout * l.nin, 0), frag((size_t)l.nout * l.nin, 0);
+    const int8_t *wb = l.w;
+    for (int g = 0, b = 0; g < l.nout / 8; g++)
+      for (; b < grp[g + 1]; b++, wb += 32)
+        for (int r = 0; r < 8; r++)
+          for (int c = 0; c < 4; c++) dense[(size_t)(8 * g + r) * l.nin + cols[b] + c] = wb[r * 4 + c];
+    const int KTn = l.nin / 64;
+    for (int rt = 0; rt < l.nout / 16; rt++)
+      for (int kt = 0; kt < KTn; kt++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 16; e++)
+            frag[(((size_t)rt * KTn + kt) * 64 + lane) * 16 + e] =
+                dense[(size_t)(16 * rt + (lane & 15)) * l.nin + 64 * kt + 16 * (lane >> 4) + e];
+    o.wmf = st.add(frag.data(), frag.size());
+  }
   if (idx || true) {
     o.grp = st.add(grp.data(), 4 * grp.size());
     o.cols = st.add(cols.data(), 2 * cols.size());
@@ -233,6 +250,7 @@ RnLinearDev resolve_linear(const uint8_t *base, const DevLinearOffsets &o, const
   if (o.is_int8) {
     d.scale = reinterpret_cast<const float *>(base + o.scale);
     d.w = reinterpret_cast<const int8_t *>(base + o.w);
+    d.wmf = reinterpret_cast<const int8_t *>(base + o.wmf);
     d.rowsum128 = reinterpret_cast<const int *>(base + o.rowsum);
     d.grp_start = reinterpret_cast<const int *>(base + o.grp);
     if (o.has_cols) d.cols = reinterpret_cast<const uint16_t *>(base + o.cols);
@@ -435,6 +453,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.pitch = carve<int>(p, N);
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
+  g.nn_act = carve<float>(p, RN_GRU * N);
   return (size_t)(p - base);
 }
 
@@ -547,6 +566,7 @@ extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
 
 extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
   if (!b || path < 0 || path > 1) return -1;
+  if (path == 1 && !rn_nn_mfma_available()) return -1;
   int old = b->nn_path;
   b->nn_path = path;
   return old;

@@ -283,3 +283,60 @@ def test_device_resident_path_with_torch_stream(model, blob_default):
     assert_bits_equal(d_out.cpu().numpy(), want["out"], "pcm")
     assert_bits_equal(d_g.cpu().numpy(), want["gains"], "gains")
     assert_bits_equal(d_vad.cpu().numpy(), want["vad"], "vad")
+
+
+# ---- batched MFMA network path (rnnoise_batch_set_nn_path(b, 1)) -------------------------------
+@pytest.mark.parametrize("n", [4, 17, 64, 65])
+def test_mfma_path_bit_exact(model, blob_default, n):
+    """int8 MFMA on zero-filled dense tiles + f32 MFMA chains = same bits as the oracle, for tile
+    counts that do and do not divide 16, with silent and non-silent streams mixed in one tile"""
+    T = 40
+    ids = [(3 * s) % 11 for s in range(n)]
+    pcm = synth.batch_pcm(ids, T, lead_silence=0)
+    pcm[:5, ::3] = 0          # every third stream starts silent
+    pcm[20:26, 1::4] = 0      # others go silent mid-way (state must freeze, src/denoise.c:474)
+    uniq = sorted({(i, s % 3 == 0, s % 4 == 1) for s, i in enumerate(ids)})
+    b = capi.Batch(model, n)
+    b.set_nn_path(1)
+    out, vad, gains = b.process(pcm)
+    cache = {}
+    for s, i in enumerate(ids):
+        key = (i, s % 3 == 0, s % 4 == 1)
+        if key not in cache:
+            o = Oracle(blob_default)
+            cache[key] = (o.run(pcm[:, s]), o.get_state())
+        want, wstate = cache[key]
+        assert_bits_equal(gains[:, s], want["gains"], f"gains stream {s}")
+        assert_bits_equal(vad[:, s], want["vad"], f"vad stream {s}")
+        assert_bits_equal(out[:, s], want["out"], f"pcm stream {s}")
+        if s < 8 or s == n - 1:
+            assert_bits_equal(b.export_state(s), wstate, f"state stream {s}")
+    assert any(w["silence"].any() for w, _ in cache.values()) and len(uniq) >= 2
+
+
+def test_mfma_and_vector_paths_agree_on_golden(model):
+    g = golden("digest_default.npz")
+    streams = (0, 1, 159, 4095)
+    pcm = synth.batch_pcm(streams, 400, lead_silence=5)
+    b = capi.Batch(model, 4)
+    b.set_nn_path(1)
+    got = gpu_run(b, pcm)
+    for i, s in enumerate(streams):
+        assert_bits_equal(got["gains"][:, i], g[f"s{s}_gains"], "gains")
+        assert_bits_equal(got["vad"][:, i], g[f"s{s}_vad"], "vad")
+        assert np.array_equal(crc_rows(got["out"][:, i]), g[f"s{s}_out_crc"])
+        assert synth.crc32(b.export_state(i)) == int(g[f"s{s}_state_crc"])
+
+
+def test_mfma_sparser_model(blob_little):
+    g = golden("digest_little.npz")
+    m = capi.Model(blob_little)
+    pcm = synth.batch_pcm((2, 31), 200, lead_silence=3)
+    b = capi.Batch(m, 2)
+    b.set_nn_path(1)
+    got = gpu_run(b, pcm)
+    for i, s in enumerate((2, 31)):
+        assert_bits_equal(got["gains"][:, i], g[f"s{s}_gains"], "gains")
+        assert np.array_equal(crc_rows(got["out"][:, i]), g[f"s{s}_out_crc"])
+    b.close()
+    m.close()
