@@ -61,6 +61,7 @@
 #define RN_DBG_BEST 1030      /* coarse best0,best1, fine best0,best1, offset, 768-pitch  */
 #define RN_DBG_XC_FINE 1040   /* [294] fine xcorr (src/pitch.c:344-361)                   */
 #define RN_DBG_DOTS 1340      /* xx, xy, yy, T, xcorr[3] of rnn_remove_doubling           */
+#define RN_DBG_CLK 1348       /* [12] shader-clock deltas of the analysis kernel's sections (profiling) */
 #define RN_DBG_FLOATS 1360
 
 #endif /* RN_LAYOUT_H */

@@ -122,33 +122,38 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
   }
 }
 
-// Band energy / correlation (src/denoise.c:90-138).  Lane k < 34 owns accumulator sum[k]:
-// first band k-1's `frac` parts in bin order, then band k's `1-frac` parts -- the exact
-// per-accumulator sequence of the reference's interleaved loop.  sums: LDS scratch [34].
-__device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float *sums,
-                                const float *__restrict__ frac_tab, int lane) {
-  if (lane < RN_NB_BANDS + 2) {
-    const int k = lane;
+// Band energy / correlation (src/denoise.c:90-138).  The reference's interleaved loop adds, for
+// every bin of band b, (1-frac)*tmp to sum[b] and frac*tmp to sum[b+1]; so accumulator k receives
+// band k-1's `frac` parts in bin order, then band k's `1-frac` parts.  Here all 64 lanes first form
+// the 800 products (each rounded exactly as in the reference) and lay them out so that accumulator
+// k's sequence is contiguous (hi part of bin -> Q[eband[b+1]+bin], lo part -> Q[eband[b]+bin]); then
+// lane k < 34 adds its sequence in order.  Padding steps add +0.0f, which changes no bit.
+// Q: LDS scratch of >= 864 floats; sums: LDS scratch [34].
+__device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float *Q, float *sums,
+                                const RnTablesDev &tb, int lane) {
+  for (int bin = lane; bin < 400; bin += WAVE) {
+    const int b = tb.band_of_bin[bin];
+    const float frac = tb.band_frac[bin];
+    const cpx x = X[bin], y = P[bin];
+    float tmp = x.r * y.r;
+    tmp += x.i * y.i;
+    Q[c_eband[b + 1] + bin] = frac * tmp;
+    Q[c_eband[b] + bin] = (1 - frac) * tmp;
+  }
+  __syncthreads();
+  {
+    const int k = lane < RN_NB_BANDS + 2 ? lane : 0;
+    const int lo = k ? c_eband[k - 1] : 0;
+    const int start = lo + c_eband[k];
+    const int len = lane < RN_NB_BANDS + 2 ? (k <= RN_NB_BANDS ? c_eband[k + 1] : 400) - lo : 0;
+    const float *q = Q + start;
     float s = 0;
-    if (k >= 1) {
-      const int b0 = c_eband[k - 1], b1 = c_eband[k];
-      for (int bin = b0; bin < b1; bin++) {
-        cpx a = X[bin], b = P[bin];
-        float tmp = a.r * b.r;
-        tmp += a.i * b.i;
-        s += frac_tab[bin] * tmp;
-      }
+#pragma unroll 4
+    for (int t = 0; t < 84; t++) {  // longest accumulator: 39 + 44 = 83 terms
+      const float v = q[t];         // start + 83 <= 839 < 864
+      s += (t < len) ? v : 0.f;
     }
-    if (k <= RN_NB_BANDS) {
-      const int b0 = c_eband[k], b1 = c_eband[k + 1];
-      for (int bin = b0; bin < b1; bin++) {
-        cpx a = X[bin], b = P[bin];
-        float tmp = a.r * b.r;
-        tmp += a.i * b.i;
-        s += (1 - frac_tab[bin]) * tmp;
-      }
-    }
-    sums[k] = s;
+    if (lane < RN_NB_BANDS + 2) sums[lane] = s;
   }
   __syncthreads();
   if (lane < RN_NB_BANDS) {
@@ -183,35 +188,81 @@ __device__ __forceinline__ float chain_dot(const float *x, const float *y, int n
   return s;
 }
 
-// src/pitch.c:44-102 (float build).  Executed uniformly by every lane (LDS broadcasts).
-__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, int &bp0, int &bp1) {
+// src/pitch.c:44-102 (float build), restructured so that only the genuinely serial part stays
+// serial:  (1) all lanes square y[] (each product rounded once, as in the reference) and form
+// d[i] = y[i+len]^2 - y[i]^2;  (2) the running energy Syy -- a float recurrence with a clamp, hence
+// order-bound -- is swept once, 4 steps per LDS transaction, leaving Syy-before-step-i in syy[i];
+// (3) the best-two selection replays the reference's sequential comparisons, but only over the lags
+// with xcorr > 0 (a ballot), which is all the reference's loop body looks at.
+// sq: scratch >= len + max_pitch (+3) floats; syy: scratch >= max_pitch rounded up to 4.
+__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, float *sq, float *syy,
+                                int &bp0, int &bp1, int lane) {
+  const int mp4 = (max_pitch + 3) & ~3;
+  for (int j = lane; j < len + mp4; j += WAVE) {
+    const float v = (j < len + max_pitch) ? y[j] : 0.f;
+    sq[j] = v * v;
+  }
+  __syncthreads();
+  for (int i = lane; i < mp4; i += WAVE) syy[i] = sq[i + len] - sq[i];
   float Syy = 1;
+  for (int j = 0; j < len; j += 4) {  // len is 240 or 480
+    const float4 v = *reinterpret_cast<const float4 *>(sq + j);
+    Syy = Syy + v.x;
+    Syy = Syy + v.y;
+    Syy = Syy + v.z;
+    Syy = Syy + v.w;
+  }
+  __syncthreads();
+  for (int i = 0; i < mp4; i += 4) {
+    const float4 d = *reinterpret_cast<const float4 *>(syy + i);
+    float4 o;
+    o.x = Syy; Syy = Syy + d.x; Syy = (1 > Syy) ? 1 : Syy;
+    o.y = Syy; Syy = Syy + d.y; Syy = (1 > Syy) ? 1 : Syy;
+    o.z = Syy; Syy = Syy + d.z; Syy = (1 > Syy) ? 1 : Syy;
+    o.w = Syy; Syy = Syy + d.w; Syy = (1 > Syy) ? 1 : Syy;
+    if (lane == 0) *reinterpret_cast<float4 *>(syy + i) = o;
+  }
+  __syncthreads();
   float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
   bp0 = 0;
   bp1 = 1;
-  for (int j = 0; j < len; j++) Syy = Syy + y[j] * y[j];
-  for (int i = 0; i < max_pitch; i++) {
-    float xc = xcorr[i];
-    if (xc > 0) {
-      float x16 = xc * 1e-12f;
-      float num = x16 * x16;
-      if (num * bd1 > bn1 * Syy) {
-        if (num * bd0 > bn0 * Syy) {
+  for (int base = 0; base < max_pitch; base += WAVE) {
+    const int i = base + lane;
+    const float xc = (i < max_pitch) ? xcorr[i] : 0.f;
+    unsigned long long mask = __ballot(xc > 0);
+    while (mask) {
+      const int bit = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int idx = base + bit;
+      const float x16 = xcorr[idx] * 1e-12f;
+      const float num = x16 * x16;
+      const float S = syy[idx];
+      if (num * bd1 > bn1 * S) {
+        if (num * bd0 > bn0 * S) {
           bn1 = bn0; bd1 = bd0; bp1 = bp0;
-          bn0 = num; bd0 = Syy; bp0 = i;
+          bn0 = num; bd0 = S; bp0 = idx;
         } else {
-          bn1 = num; bd1 = Syy; bp1 = i;
+          bn1 = num; bd1 = S; bp1 = idx;
         }
       }
     }
-    Syy += y[i + len] * y[i + len] - y[i] * y[i];
-    Syy = (1 > Syy) ? 1 : Syy;
   }
+  __syncthreads();
 }
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
   return (float)(xy / sqrt((double)(1 + xx * yy)));
 }
+
+// profiling taps (only when the debug record is armed): shader-clock delta since the previous tap
+#define CLK_TAP(idx)                                                         \
+  do {                                                                       \
+    if (dbg) {                                                               \
+      unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+      if (lane == 0) dbg[RN_DBG_CLK + (idx)] = (float)(now_ - clk_prev);     \
+      clk_prev = now_;                                                       \
+    }                                                                        \
+  } while (0)
 
 struct AnalysisLds {
   float pb[RN_PITCH_BUF_SIZE];  // pitch_buf after the shift (src/denoise.c:359-360)
@@ -236,6 +287,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
   float *Ex = L.Ex, *Ep = L.Ep, *Exp = L.Exp, *Ly = L.Ly, *sums = L.sums;
   float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
+  unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
   // ---- load: shifted pitch buffer + raw input ----
   const float *pb_old = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
@@ -244,6 +296,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) L.pb[RN_PITCH_BUF_SIZE - RN_FRAME_SIZE + i] = xin[i];
   __syncthreads();
 
+  CLK_TAP(0);  // load
   // ---- rnn_biquad (src/denoise.c:409-419, coefficients :469-470): strictly serial, in place ----
   {
     float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
@@ -277,6 +330,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     for (int i = lane; i < RN_PITCH_BUF_SIZE; i += WAVE) pb_new[i] = L.pb[i];
   }
 
+  CLK_TAP(1);  // biquad + write-back
   // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
@@ -292,8 +346,9 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     gX[2 * i + 1] = v.i;
   }
   __syncthreads();
-  band_accumulate(Ex, L.X, L.X, sums, tb.band_frac, lane);
+  band_accumulate(Ex, L.X, L.X, L.xlp, sums, tb, lane);
 
+  CLK_TAP(2);  // window + FFT(X) + Ex
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
   for (int i = lane; i < 864; i += WAVE) {
     float v;
@@ -382,14 +437,20 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   }
   __syncthreads();
 
+  CLK_TAP(3);  // downsample + autocorr + LPC + FIR
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = L.xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
   for (int j = lane; j < 432; j += WAVE) L.y4[j] = L.xlp[2 * j];
   __syncthreads();
   for (int lag = lane; lag < 147; lag += WAVE) L.xc[lag] = chain_dot(L.y4 + 192, L.y4 + lag, 240);
   __syncthreads();
+  // scratch inside the idle FFT area: squares [0..863], running energies [864..1159],
+  // yy_lookup [1163..1547] (index i at 1163+i so that i = 4m+1 is 16-byte aligned), dots [1552..1583]
+  float *scr_sq = reinterpret_cast<float *>(L.F), *scr_syy = scr_sq + 864;
   int bp0, bp1;
-  find_best_pitch(L.xc, L.y4, 240, 147, bp0, bp1);
+  CLK_TAP(4);  // coarse xcorr
+  find_best_pitch(L.xc, L.y4, 240, 147, scr_sq, scr_syy, bp0, bp1, lane);
+  CLK_TAP(5);  // coarse best-pitch scan
   if (dbg) {
     for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = L.xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
@@ -405,7 +466,9 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     }
   }
   __syncthreads();
-  find_best_pitch(L.xc, L.xlp, 480, 294, bp0, bp1);
+  CLK_TAP(6);  // fine xcorr
+  find_best_pitch(L.xc, L.xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
+  CLK_TAP(7);  // fine best-pitch scan
   int offset = 0;
   if (bp0 > 0 && bp0 < 293) {
     float a = L.xc[bp0 - 1], b = L.xc[bp0], c = L.xc[bp0 + 1];
@@ -424,8 +487,8 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     const int maxperiod = 384, minperiod = 30, N = 480, minperiod0 = RN_PITCH_MIN_PERIOD;
     const int *sc = c_second_check;
     const float *x = L.xlp + maxperiod;
-    float *yyl = reinterpret_cast<float *>(L.F);  // [385]
-    float *dots = reinterpret_cast<float *>(L.F) + 400;  // [32]
+    float *yyl = scr_sq + 1163;   // [385]
+    float *dots = scr_sq + 1552;  // [32]
     int T0 = pitch_index / 2;
     const int prev_period = g.last_period[s] / 2;
     const float prev_gain = g.last_gain[s];
@@ -448,16 +511,27 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     __syncthreads();
     const float xx = dots[0];
     float xy = dots[1];
-    {  // yy_lookup (pitch.c:449-456): serial running energy
+    CLK_TAP(8);  // 30 candidate dot products of remove_doubling
+    {  // yy_lookup (pitch.c:449-456): yy = (yy + x[-i]^2) - x[N-i]^2, clamped copy stored.  Squares are
+       // formed by all lanes first; the recurrence is swept 4 steps per LDS transaction.
+      for (int j = lane; j < 864; j += WAVE) scr_sq[j] = L.xlp[j] * L.xlp[j];
+      __syncthreads();
       float yy = xx;
       if (lane == 0) yyl[0] = xx;
-      for (int i = 1; i <= maxperiod; i++) {
-        yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
-        if (lane == 0) yyl[i] = (0 > yy) ? 0 : yy;
+      for (int i = 1; i <= maxperiod; i += 4) {  // x[-i] = xlp[384-i], x[N-i] = xlp[864-i]
+        const float4 a = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - i - 3);      // [384-i-3 .. 384-i]
+        const float4 b = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - i - 3);  // [864-i-3 .. 864-i]
+        float4 o;
+        yy = yy + a.w - b.w; o.x = (0 > yy) ? 0 : yy;
+        yy = yy + a.z - b.z; o.y = (0 > yy) ? 0 : yy;
+        yy = yy + a.y - b.y; o.z = (0 > yy) ? 0 : yy;
+        yy = yy + a.x - b.x; o.w = (0 > yy) ? 0 : yy;
+        if (lane == 0) *reinterpret_cast<float4 *>(yyl + i) = o;
       }
     }
     __syncthreads();
     float yy = yyl[T0];
+    CLK_TAP(9);  // yy_lookup running energy
     float best_xy = xy, best_yy = yy;
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
     const float g0 = pitch_gain(xy, xx, yy);
@@ -511,6 +585,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     g.pitch[s] = pitch_index;
   }
 
+  CLK_TAP(10);  // doubling decisions + 3 final dots
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
@@ -524,8 +599,8 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     gP[2 * i] = v.r;
     gP[2 * i + 1] = v.i;
   }
-  band_accumulate(Ep, L.F, L.F, sums, tb.band_frac, lane);
-  band_accumulate(Exp, L.X, L.F, sums, tb.band_frac, lane);
+  band_accumulate(Ep, L.F, L.F, L.xlp, sums, tb, lane);
+  band_accumulate(Exp, L.X, L.F, L.xlp, sums, tb, lane);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
@@ -570,6 +645,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     feat[2 * RN_NB_BANDS] = silence ? 0.f : (float)(.01 * (double)(pitch_index - 300));
     g.silence[s] = silence;
   }
+  CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
 }
 
 struct SynthLds {
@@ -620,7 +696,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       L.X[i] = x;
     }
     __syncthreads();
-    band_accumulate(newE, L.X, L.X, sums, tb.band_frac, lane);
+    band_accumulate(newE, L.X, L.X, reinterpret_cast<float *>(L.F), sums, tb, lane);
     if (lane < RN_NB_BANDS) {
       norm[lane] = (float)sqrt((double)dE[lane] / (1e-8 + (double)newE[lane]));  // :447-449
       // gain smoothing (src/denoise.c:479-487)

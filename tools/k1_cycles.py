@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Print the shader-clock breakdown of rn_analysis_kernel (debug taps) for a lone wave and under load."""
+import lzma, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rnnoise_amd import capi, synth
+NAMES = ["load", "biquad+wb", "win+FFT(X)+Ex", "downsample..FIR", "coarse xcorr", "coarse scan", "fine xcorr",
+         "fine scan", "doubling dots", "yy_lookup", "decide+3dots", "P FFT+Ep+Exp+feat"]
+blob = lzma.decompress(open(os.path.join(ROOT, "tests/golden/default.blob.xz"), "rb").read())
+m = capi.Model(blob)
+for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
+    b = capi.Batch(m, n)
+    b.debug_pitch(arm_only=True)
+    pcm = np.ascontiguousarray(np.tile(synth.batch_pcm(range(min(n, 16)), 6), (1, (n + 15) // 16, 1))[:, :n])
+    b.process(pcm)
+    d = b.debug_pitch()
+    clk = d[:, 1348:1360]
+    print(f"--- N={n}: mean shader clocks per section over streams (total {clk.sum(1).mean():.0f}) ---")
+    for k, name in enumerate(NAMES):
+        print(f"  {name:<20} {clk[:, k].mean():>10.0f}  {100 * clk[:, k].mean() / clk.sum(1).mean():5.1f}%")
+    b.close()
