@@ -264,96 +264,130 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // 
     }                                                                        \
   } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// K0: rnn_biquad (src/denoise.c:409-419, coefficients :469-470), transposed: lane = stream.
+// The recurrence is strictly serial per stream (every step rounds its state to float), so the
+// wave-per-frame kernel would idle 63 of 64 lanes for 480 steps; here 64 streams advance in
+// lock-step instead.  Output goes straight into the stream's pitch ring (slot `slot`).
+// a0*yi and a1*yi are products of two 24-bit significands, exact in double, so
+// fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
+  const int s = blockIdx.x * WAVE + threadIdx.x;
+  if (s >= g.n_streams) return;
+  const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
+  const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
+  float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
+  const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
+  float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
+  float4 nxt = x[0];
+  for (int i = 0; i < RN_FRAME_SIZE / 4; i++) {
+    const float4 v = nxt;
+    if (i + 1 < RN_FRAME_SIZE / 4) nxt = x[i + 1];
+    float4 o;
+#define HP_STEP(xi, yo)                                              \
+    {                                                                \
+      const float yi = (xi) + m0;                                    \
+      const double xd = (double)(xi), yd = (double)yi;               \
+      m0 = (float)((double)m1 + fma(na0, yd, b0d * xd));             \
+      m1 = (float)fma(na1, yd, xd);                                  \
+      (yo) = yi;                                                     \
+    }
+    HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+#undef HP_STEP
+    y[i] = o;
+  }
+  g.mem_hp[2 * s] = m0;
+  g.mem_hp[2 * s + 1] = m1;
+}
+
+// dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
+// x 16-byte aligned (identical for all lanes), y arbitrary.  The next 8 operand pairs are fetched
+// from LDS while the current 8 are being added, so the LDS round trip is off the chain.
+__device__ __forceinline__ float chain_dot8(const float *x, const float *y, int n) {
+  float s = 0;
+  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
+  float ya[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) ya[k] = y[k];
+  for (int i = 0; i < n; i += 8) {
+    const int nx = (i + 8 < n) ? i + 8 : i;
+    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
+    float yn[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) yn[k] = y[nx + k];
+    s = s + xa.x * ya[0];
+    s = s + xa.y * ya[1];
+    s = s + xa.z * ya[2];
+    s = s + xa.w * ya[3];
+    s = s + xb.x * ya[4];
+    s = s + xb.y * ya[5];
+    s = s + xb.z * ya[6];
+    s = s + xb.w * ya[7];
+    xa = xc;
+    xb = xd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ya[k] = yn[k];
+  }
+  return s;
+}
+
 struct AnalysisLds {
-  float pb[RN_PITCH_BUF_SIZE];  // pitch_buf after the shift (src/denoise.c:359-360)
-  float xlp[864];               // 2x decimated, LPC-whitened (src/pitch.c:146-214)
-  cpx F[RN_WINDOW_SIZE];        // FFT work area; also yy_lookup scratch
-  cpx X[RN_FREQ_SIZE + 1];      // spectrum of the current frame, kept for the X.P correlation
-  float y4[432];                // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
-  float xc[296];                // xcorr[] of pitch_search
+  cpx F[RN_WINDOW_SIZE];        // FFT work area; scratch for the pitch analysis in between
+  float xlp[864];               // 2x decimated, LPC-whitened (src/pitch.c:146-214); band-product scratch
   float sums[40];               // band accumulators (34 used)
   float Ex[RN_NB_BANDS], Ep[RN_NB_BANDS], Exp[RN_NB_BANDS], Ly[RN_NB_BANDS];
 };
+// float offsets inside the idle FFT area during the pitch analysis
+#define SCR_SQ 0      // [864]  squares of y4 / xlp
+#define SCR_SYY 864   // [296]  running energies of find_best_pitch
+#define SCR_YYL 1163  // [385]  yy_lookup; index i lives at SCR_YYL+i so that i = 4m+1 is 16-byte aligned
+#define SCR_DOTS 1552 // [32]
+#define SCR_Y4 1164   // [432]  4x-decimated signal, dead before yy_lookup/dots are written
+#define SCR_XC 1600   // [296]  xcorr[] of pitch_search
 
 // ---------------------------------------------------------------------------------------------
-// K1: rnn_biquad + rnn_compute_frame_features (src/denoise.c:471-472, 347-398, 409-419)
-// grid = n_streams blocks of one wavefront.
+// K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
+// into the pitch ring.  grid = n_streams blocks of one wavefront; ~12 KB of LDS per wave.
+// `ring0` = physical ring position of pitch_buf[0] (src/denoise.c:359-360 shift = ring rotation).
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, int parity) {
+rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x;
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
   float *Ex = L.Ex, *Ep = L.Ep, *Exp = L.Exp, *Ly = L.Ly, *sums = L.sums;
+  float *scr = reinterpret_cast<float *>(L.F);
   float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
+#define PB(i) ring[(ring0 + (i)) % RN_RING_SIZE]  // pitch_buf[i], i in [0, 1728)
 
-  // ---- load: shifted pitch buffer + raw input ----
-  const float *pb_old = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
-  for (int i = lane; i < RN_PITCH_BUF_SIZE - RN_FRAME_SIZE; i += WAVE) L.pb[i] = pb_old[i + RN_FRAME_SIZE];
-  const float *xin = in + (size_t)s * RN_FRAME_SIZE;
-  for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) L.pb[RN_PITCH_BUF_SIZE - RN_FRAME_SIZE + i] = xin[i];
-  __syncthreads();
-
-  CLK_TAP(0);  // load
-  // ---- rnn_biquad (src/denoise.c:409-419, coefficients :469-470): strictly serial, in place ----
-  {
-    float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
-    const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f, b1 = 1.f;
-    float *x = L.pb + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE;
-    for (int i = 0; i < RN_FRAME_SIZE; i += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = x[i + u];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        float xi = v[u];
-        float yi = xi + m0;
-        m0 = (float)((double)m1 + ((double)b0 * (double)xi - (double)a0 * (double)yi));
-        m1 = (float)((double)b1 * (double)xi - (double)a1 * (double)yi);
-        v[u] = yi;
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) x[i + u] = v[u];
-      }
-    }
-    if (lane == 0) {
-      g.mem_hp[2 * s] = m0;
-      g.mem_hp[2 * s + 1] = m1;
-    }
-  }
-  __syncthreads();
-  {  // write the shifted pitch buffer back
-    float *pb_new = g.pitch_buf + (size_t)s * RN_PITCH_BUF_SIZE;
-    for (int i = lane; i < RN_PITCH_BUF_SIZE; i += WAVE) pb_new[i] = L.pb[i];
-  }
-
-  CLK_TAP(1);  // biquad + write-back
+  CLK_TAP(0);
+  CLK_TAP(1);
   // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-    float v = L.pb[RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i] * w;
+    float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i) * w;
     L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
   fft960_lds(L.F, tw, lane);
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
     cpx v = L.F[i];
-    L.X[i] = v;
     gX[2 * i] = v.r;
     gX[2 * i + 1] = v.i;
   }
-  __syncthreads();
-  band_accumulate(Ex, L.X, L.X, L.xlp, sums, tb, lane);
+  band_accumulate(Ex, L.F, L.F, L.xlp, sums, tb, lane);
 
   CLK_TAP(2);  // window + FFT(X) + Ex
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
   for (int i = lane; i < 864; i += WAVE) {
     float v;
-    if (i == 0) v = .5f * (.5f * (L.pb[1]) + L.pb[0]);
-    else v = .5f * (.5f * (L.pb[2 * i - 1] + L.pb[2 * i + 1]) + L.pb[2 * i]);
+    if (i == 0) v = .5f * (.5f * (PB(1)) + PB(0));
+    else v = .5f * (.5f * (PB(2 * i - 1) + PB(2 * i + 1)) + PB(2 * i));
     L.xlp[i] = v;
   }
   __syncthreads();
@@ -363,7 +397,8 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     float ack = 0;
     if (lane < 5) {
       const int k = lane;
-      float sacc = chain_dot(L.xlp, L.xlp + k, 860), d = 0;
+      float sacc = chain_dot8(L.xlp, L.xlp + k, 856), d = 0;
+      for (int i = 856; i < 860; i++) sacc = sacc + L.xlp[i] * L.xlp[i + k];
       for (int i = k + 860; i < 864; i++) d = d + L.xlp[i] * L.xlp[i - k];
       ack = sacc + d;
     }
@@ -440,44 +475,43 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   CLK_TAP(3);  // downsample + autocorr + LPC + FIR
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = L.xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
-  for (int j = lane; j < 432; j += WAVE) L.y4[j] = L.xlp[2 * j];
+  float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *scr_sq = scr + SCR_SQ, *scr_syy = scr + SCR_SYY;
+  // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
+  for (int j = lane; j < 432; j += WAVE) y4[j] = L.xlp[2 * j];
   __syncthreads();
-  for (int lag = lane; lag < 147; lag += WAVE) L.xc[lag] = chain_dot(L.y4 + 192, L.y4 + lag, 240);
+  for (int lag = lane; lag < 147; lag += WAVE) xc[lag] = chain_dot8(y4 + 192, y4 + lag, 240);
   __syncthreads();
-  // scratch inside the idle FFT area: squares [0..863], running energies [864..1159],
-  // yy_lookup [1163..1547] (index i at 1163+i so that i = 4m+1 is 16-byte aligned), dots [1552..1583]
-  float *scr_sq = reinterpret_cast<float *>(L.F), *scr_syy = scr_sq + 864;
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
-  find_best_pitch(L.xc, L.y4, 240, 147, scr_sq, scr_syy, bp0, bp1, lane);
+  find_best_pitch(xc, y4, 240, 147, scr_sq, scr_syy, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
   if (dbg) {
-    for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = L.xc[i];
+    for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
   }
   __syncthreads();
-  for (int i = lane; i < 294; i += WAVE) L.xc[i] = 0;
+  for (int i = lane; i < 294; i += WAVE) xc[i] = 0;
   __syncthreads();
   if (lane < 10) {
     int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
     if (c >= 0 && c < 294) {
-      float sum = chain_dot(L.xlp + 384, L.xlp + c, 480);
-      L.xc[c] = (-1 > sum) ? -1 : sum;
+      float sum = chain_dot8(L.xlp + 384, L.xlp + c, 480);
+      xc[c] = (-1 > sum) ? -1 : sum;
     }
   }
   __syncthreads();
   CLK_TAP(6);  // fine xcorr
-  find_best_pitch(L.xc, L.xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
+  find_best_pitch(xc, L.xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch scan
   int offset = 0;
   if (bp0 > 0 && bp0 < 293) {
-    float a = L.xc[bp0 - 1], b = L.xc[bp0], c = L.xc[bp0 + 1];
+    float a = xc[bp0 - 1], b = xc[bp0], c = xc[bp0 + 1];
     if ((c - a) > .7f * (b - a)) offset = 1;
     else if ((a - c) > .7f * (b - c)) offset = -1;
   }
   int pitch_index = RN_PITCH_MAX_PERIOD - (2 * bp0 - offset);
   if (dbg) {
-    for (int i = lane; i < 294; i += WAVE) dbg[RN_DBG_XC_FINE + i] = L.xc[i];
+    for (int i = lane; i < 294; i += WAVE) dbg[RN_DBG_XC_FINE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST + 2] = bp0; dbg[RN_DBG_BEST + 3] = bp1; dbg[RN_DBG_BEST + 4] = offset; dbg[RN_DBG_BEST + 5] = pitch_index; }
   }
 
@@ -487,13 +521,14 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     const int maxperiod = 384, minperiod = 30, N = 480, minperiod0 = RN_PITCH_MIN_PERIOD;
     const int *sc = c_second_check;
     const float *x = L.xlp + maxperiod;
-    float *yyl = scr_sq + 1163;   // [385]
-    float *dots = scr_sq + 1552;  // [32]
+    float *yyl = scr + SCR_YYL;
+    float *dots = scr + SCR_DOTS;
     int T0 = pitch_index / 2;
     const int prev_period = g.last_period[s] / 2;
     const float prev_gain = g.last_gain[s];
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
+    __syncthreads();  // y4 is dead from here on; its area becomes yy_lookup / dots
     // all candidate dot products at once: lane 0 xx, lane 1 xy(T0), lanes 2.. (k, T1 / T1b)
     {
       int off = -1;
@@ -506,27 +541,42 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
         else T1b = (2 * sc[k] * T0 + k) / (2 * k);
         off = ((lane - 2) & 1) ? T1b : T1;
       }
-      if (off >= 0) dots[lane] = chain_dot(x, x - off, N);
+      if (off >= 0) dots[lane] = chain_dot8(x, x - off, N);
     }
     __syncthreads();
     const float xx = dots[0];
     float xy = dots[1];
     CLK_TAP(8);  // 30 candidate dot products of remove_doubling
     {  // yy_lookup (pitch.c:449-456): yy = (yy + x[-i]^2) - x[N-i]^2, clamped copy stored.  Squares are
-       // formed by all lanes first; the recurrence is swept 4 steps per LDS transaction.
+       // formed by all lanes first; the recurrence is swept 8 steps per iteration with the next
+       // operands already in flight.
       for (int j = lane; j < 864; j += WAVE) scr_sq[j] = L.xlp[j] * L.xlp[j];
       __syncthreads();
       float yy = xx;
       if (lane == 0) yyl[0] = xx;
-      for (int i = 1; i <= maxperiod; i += 4) {  // x[-i] = xlp[384-i], x[N-i] = xlp[864-i]
-        const float4 a = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - i - 3);      // [384-i-3 .. 384-i]
-        const float4 b = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - i - 3);  // [864-i-3 .. 864-i]
-        float4 o;
-        yy = yy + a.w - b.w; o.x = (0 > yy) ? 0 : yy;
-        yy = yy + a.z - b.z; o.y = (0 > yy) ? 0 : yy;
-        yy = yy + a.y - b.y; o.z = (0 > yy) ? 0 : yy;
-        yy = yy + a.x - b.x; o.w = (0 > yy) ? 0 : yy;
-        if (lane == 0) *reinterpret_cast<float4 *>(yyl + i) = o;
+      // x[-i] = xlp[384-i], x[N-i] = xlp[864-i]; i = 1..384
+      float4 a0 = *reinterpret_cast<const float4 *>(scr_sq + 380), b0 = *reinterpret_cast<const float4 *>(scr_sq + 860);
+      float4 a1 = *reinterpret_cast<const float4 *>(scr_sq + 376), b1 = *reinterpret_cast<const float4 *>(scr_sq + 856);
+      for (int i = 1; i <= maxperiod; i += 8) {
+        const int nb = (i + 8 <= maxperiod) ? i + 8 : i;
+        const float4 na0 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - nb - 3);
+        const float4 nb0 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - nb - 3);
+        const float4 na1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - nb - 7);
+        const float4 nb1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - nb - 7);
+        float4 o0, o1;
+        yy = yy + a0.w - b0.w; o0.x = (0 > yy) ? 0 : yy;
+        yy = yy + a0.z - b0.z; o0.y = (0 > yy) ? 0 : yy;
+        yy = yy + a0.y - b0.y; o0.z = (0 > yy) ? 0 : yy;
+        yy = yy + a0.x - b0.x; o0.w = (0 > yy) ? 0 : yy;
+        yy = yy + a1.w - b1.w; o1.x = (0 > yy) ? 0 : yy;
+        yy = yy + a1.z - b1.z; o1.y = (0 > yy) ? 0 : yy;
+        yy = yy + a1.y - b1.y; o1.z = (0 > yy) ? 0 : yy;
+        yy = yy + a1.x - b1.x; o1.w = (0 > yy) ? 0 : yy;
+        if (lane == 0) {
+          *reinterpret_cast<float4 *>(yyl + i) = o0;
+          *reinterpret_cast<float4 *>(yyl + i + 4) = o1;
+        }
+        a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
       }
     }
     __syncthreads();
@@ -566,7 +616,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     if (best_yy <= best_xy) pg = 1.f;
     else pg = best_xy / (best_yy + 1);
     __syncthreads();
-    if (lane < 3) dots[lane] = chain_dot(x, x - (T + lane - 1), N);
+    if (lane < 3) dots[lane] = chain_dot8(x, x - (T + lane - 1), N);
     __syncthreads();
     float xc0 = dots[0], xc1 = dots[1], xc2 = dots[2];
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS + 3] = T; dbg[RN_DBG_DOTS + 4] = xc0; dbg[RN_DBG_DOTS + 5] = xc1; dbg[RN_DBG_DOTS + 6] = xc2; }
@@ -589,7 +639,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-    float v = L.pb[RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i] * w;
+    float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i) * w;
     L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
   fft960_lds(L.F, tw, lane);
@@ -600,7 +650,8 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     gP[2 * i + 1] = v.i;
   }
   band_accumulate(Ep, L.F, L.F, L.xlp, sums, tb, lane);
-  band_accumulate(Exp, L.X, L.F, L.xlp, sums, tb, lane);
+  // X is read back from HBM/L2 (this block wrote it; the barriers since then make it visible)
+  band_accumulate(Exp, reinterpret_cast<const cpx *>(gX), L.F, L.xlp, sums, tb, lane);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
@@ -646,6 +697,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, const float *__restrict__ in, i
     g.silence[s] = silence;
   }
   CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
+#undef PB
 }
 
 struct SynthLds {
@@ -746,9 +798,13 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
 }
 
 // host-visible launch helpers -----------------------------------------------------------------
-extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, const float *in, int parity,
-                                         hipStream_t st) {
-  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, in, parity);
+// `slot` = ring slot that receives this frame; pitch_buf[0] then sits at ring position
+// ((slot+1)*480 + 192) mod 1920 (the buffer holds the latest 1728 = 3.6 frames).
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, const float *in, int slot,
+                                         int parity, hipStream_t st) {
+  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot);
+  const int ring0 = (((slot + 1) % RN_RING_SLOTS) * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
+  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, ring0, parity);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int parity,

@@ -16,6 +16,8 @@
 #include "../../include/rn_layout.h"
 
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
+#define RN_RING_SLOTS 4     // pitch ring: 4 frames of 480 hold the 1728-sample pitch_buf without shifting
+#define RN_RING_SIZE (RN_RING_SLOTS * RN_FRAME_SIZE)
 
 struct RnTablesDev {
   const float *half_window;   // [480]   src/rnnoise_tables.c:570 (by formula)
@@ -50,7 +52,7 @@ struct RnGroupDev {
   int n_streams;
   // persistent per-stream state
   float *mem_hp;       // [N][2]
-  float *pitch_buf;    // [N][1728]
+  float *pitch_ring;   // [N][1920] ring of high-passed frames; pitch_buf (src/denoise.c:76) = its latest 1728 samples
   float *synth_mem;    // [N][480]
   float *last_gain;    // [N]
   int *last_period;    // [N]

@@ -18,7 +18,7 @@
 #include "rcp_lut_x86.h"
 #include "rn_dev.h"
 
-extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, const float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, const float *, int, int, hipStream_t);
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
@@ -355,6 +355,7 @@ struct RNNModel {
 struct RNNoiseBatch {
   RNNModel *model = nullptr;
   int device = 0, n = 0, parity = 0, nn_path = 0;
+  int ring_slot = 0;  // pitch-ring slot the next frame is written to
   void *arena = nullptr;
   size_t arena_bytes = 0;
   RnGroupDev g{};
@@ -435,7 +436,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   size_t N = n;
   g.n_streams = n;
   g.mem_hp = carve<float>(p, 2 * N);
-  g.pitch_buf = carve<float>(p, RN_PITCH_BUF_SIZE * N);
+  g.pitch_ring = carve<float>(p, RN_RING_SIZE * N);
   g.synth_mem = carve<float>(p, RN_FRAME_SIZE * N);
   g.last_gain = carve<float>(p, N);
   g.last_period = carve<int>(p, N);
@@ -561,6 +562,7 @@ extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   HIP_OK(hipSetDevice(b->device));
   HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
   b->parity = 0;
+  b->ring_slot = 0;
   return 0;
 }
 
@@ -584,7 +586,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     g.gains = d_gains ? d_gains + f * N * RN_NB_BANDS : b->scratch_gains;
     {
       ScopedEvent ev(b, st, 0);
-      HIP_OK(rn_launch_analysis(&g, &b->tb, d_in + f * N * RN_FRAME_SIZE, b->parity, st));
+      HIP_OK(rn_launch_analysis(&g, &b->tb, d_in + f * N * RN_FRAME_SIZE, b->ring_slot, b->parity, st));
     }
     {
       ScopedEvent ev(b, st, 1);
@@ -596,6 +598,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, b->parity, st));
     }
     b->parity ^= 1;
+    b->ring_slot = (b->ring_slot + 1) % RN_RING_SLOTS;
     b->launches += b->timing ? 1 : 0;
   }
   return 0;
@@ -637,7 +640,12 @@ extern "C" int rnnoise_batch_export_state(RNNoiseBatch *b, int s, float *f) {
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
   const int last = b->parity ^ 1;  // slot written by the most recent frame = the "delayed" spectra
-  D2H(f + RN_OFF_PITCH_BUF, g.pitch_buf + S * RN_PITCH_BUF_SIZE, RN_PITCH_BUF_SIZE);
+  {  // un-rotate the pitch ring: pitch_buf[i] = ring[(ring0 + i) % 1920]
+    float ring[RN_RING_SIZE];
+    D2H(ring, g.pitch_ring + S * RN_RING_SIZE, RN_RING_SIZE);
+    const int ring0 = (b->ring_slot * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
+    for (int i = 0; i < RN_PITCH_BUF_SIZE; i++) f[RN_OFF_PITCH_BUF + i] = ring[(ring0 + i) % RN_RING_SIZE];
+  }
   memcpy(f + RN_OFF_ANALYSIS, f + RN_OFF_PITCH_BUF + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, RN_FRAME_SIZE * 4);
   D2H(f + RN_OFF_SYNTHESIS, g.synth_mem + S * RN_FRAME_SIZE, RN_FRAME_SIZE);
   D2H(f + RN_OFF_LAST_GAIN, g.last_gain + S, 1);
@@ -664,7 +672,12 @@ extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
   const int last = b->parity ^ 1;
-  H2D(g.pitch_buf + S * RN_PITCH_BUF_SIZE, f + RN_OFF_PITCH_BUF, RN_PITCH_BUF_SIZE);
+  {
+    float ring[RN_RING_SIZE] = {0};
+    const int ring0 = (b->ring_slot * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
+    for (int i = 0; i < RN_PITCH_BUF_SIZE; i++) ring[(ring0 + i) % RN_RING_SIZE] = f[RN_OFF_PITCH_BUF + i];
+    H2D(g.pitch_ring + S * RN_RING_SIZE, ring, RN_RING_SIZE);
+  }
   H2D(g.synth_mem + S * RN_FRAME_SIZE, f + RN_OFF_SYNTHESIS, RN_FRAME_SIZE);
   H2D(g.last_gain + S, f + RN_OFF_LAST_GAIN, 1);
   H2D(g.last_period + S, f + RN_OFF_LAST_PERIOD, 1);
