@@ -8,7 +8,8 @@ stream of the batch advances by one 480-sample frame (analysis -> network -> syn
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--nn vector|mfma]
 
 Workload at N=1: BASELINE.json configs[1] -- 4096 concurrent streams on one MI355X, default
-architecture, int8 model.  With --gpus N every rank owns its own S streams (independent
+architecture, int8 model -- run on the faster of the two bit-identical network paths (batched
+MFMA; `--nn vector` selects the v_dot4 path configs[1] names, `--streams 65536` is configs[2]).  With --gpus N every rank owns its own S streams (independent
 streams shard trivially, SURVEY 8e: "weak" scaling, no data-path collective); the only
 collectives are the barrier and the max/sum over ranks of (elapsed, frames).
 
@@ -115,7 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU (configs[1]: 4096)")
-    ap.add_argument("--nn", choices=["vector", "mfma"], default=os.environ.get("RNNOISE_AMD_NN", "vector"))
+    ap.add_argument("--nn", choices=["vector", "mfma"], default=os.environ.get("RNNOISE_AMD_NN", "mfma"),
+                    help="network path: batched MFMA (default) or the v_dot4 vector path; identical bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -216,10 +216,10 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
   for (int i = 0; i < mp4; i += 4) {
     const float4 d = *reinterpret_cast<const float4 *>(syy + i);
     float4 o;
-    o.x = Syy; Syy = Syy + d.x; Syy = (1 > Syy) ? 1 : Syy;
-    o.y = Syy; Syy = Syy + d.y; Syy = (1 > Syy) ? 1 : Syy;
-    o.z = Syy; Syy = Syy + d.z; Syy = (1 > Syy) ? 1 : Syy;
-    o.w = Syy; Syy = Syy + d.w; Syy = (1 > Syy) ? 1 : Syy;
+    o.x = Syy; Syy = fmaxf(1.f, Syy + d.x);  // MAX32(1, Syy): same value for every non-NaN Syy
+    o.y = Syy; Syy = fmaxf(1.f, Syy + d.y);
+    o.z = Syy; Syy = fmaxf(1.f, Syy + d.z);
+    o.w = Syy; Syy = fmaxf(1.f, Syy + d.w);
     if (lane == 0) *reinterpret_cast<float4 *>(syy + i) = o;
   }
   __syncthreads();
@@ -343,9 +343,9 @@ struct AnalysisLds {
 #define SCR_SQ 0      // [864]  squares of y4 / xlp
 #define SCR_SYY 864   // [296]  running energies of find_best_pitch
 #define SCR_YYL 1163  // [385]  yy_lookup; index i lives at SCR_YYL+i so that i = 4m+1 is 16-byte aligned
-#define SCR_DOTS 1552 // [32]
+#define SCR_DOTS 1552 // [64]  (overlaps the tail of y4, which is dead by then)
 #define SCR_Y4 1164   // [432]  4x-decimated signal, dead before yy_lookup/dots are written
-#define SCR_XC 1600   // [296]  xcorr[] of pitch_search
+#define SCR_XC 1620   // [296]  xcorr[] of pitch_search
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
@@ -529,7 +529,11 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
     __syncthreads();  // y4 is dead from here on; its area becomes yy_lookup / dots
-    // all candidate dot products at once: lane 0 xx, lane 1 xy(T0), lanes 2.. (k, T1 / T1b)
+    // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
+    // independent serial sum, so computing it speculatively changes no bit):
+    //   lane 0: xx;  lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
+    //   lanes 32..61: the +-1 neighbours of every period the decision loop can end on
+    //   (T0 and T1(k)), needed by the final 3-point refinement (pitch.c:511-512).
     {
       int off = -1;
       if (lane == 0) off = 0;
@@ -540,6 +544,11 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
         if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
         else T1b = (2 * sc[k] * T0 + k) / (2 * k);
         off = ((lane - 2) & 1) ? T1b : T1;
+      } else if (lane >= 32 && lane < 62) {
+        const int c = (lane - 32) >> 1;  // candidate 0: T0; candidate c >= 1: T1(k = c + 1)
+        const int Tc = c ? (2 * T0 + (c + 1)) / (2 * (c + 1)) : T0;
+        off = Tc + (((lane - 32) & 1) ? 1 : -1);
+        if (off < 0) off = 0;  // only for candidates the decision loop never selects (T1 < minperiod)
       }
       if (off >= 0) dots[lane] = chain_dot8(x, x - off, N);
     }
@@ -564,14 +573,14 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
         const float4 na1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - nb - 7);
         const float4 nb1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - nb - 7);
         float4 o0, o1;
-        yy = yy + a0.w - b0.w; o0.x = (0 > yy) ? 0 : yy;
-        yy = yy + a0.z - b0.z; o0.y = (0 > yy) ? 0 : yy;
-        yy = yy + a0.y - b0.y; o0.z = (0 > yy) ? 0 : yy;
-        yy = yy + a0.x - b0.x; o0.w = (0 > yy) ? 0 : yy;
-        yy = yy + a1.w - b1.w; o1.x = (0 > yy) ? 0 : yy;
-        yy = yy + a1.z - b1.z; o1.y = (0 > yy) ? 0 : yy;
-        yy = yy + a1.y - b1.y; o1.z = (0 > yy) ? 0 : yy;
-        yy = yy + a1.x - b1.x; o1.w = (0 > yy) ? 0 : yy;
+        yy = yy + a0.w - b0.w; o0.x = fmaxf(0.f, yy);
+        yy = yy + a0.z - b0.z; o0.y = fmaxf(0.f, yy);
+        yy = yy + a0.y - b0.y; o0.z = fmaxf(0.f, yy);
+        yy = yy + a0.x - b0.x; o0.w = fmaxf(0.f, yy);
+        yy = yy + a1.w - b1.w; o1.x = fmaxf(0.f, yy);
+        yy = yy + a1.z - b1.z; o1.y = fmaxf(0.f, yy);
+        yy = yy + a1.y - b1.y; o1.z = fmaxf(0.f, yy);
+        yy = yy + a1.x - b1.x; o1.w = fmaxf(0.f, yy);
         if (lane == 0) {
           *reinterpret_cast<float4 *>(yyl + i) = o0;
           *reinterpret_cast<float4 *>(yyl + i + 4) = o1;
@@ -615,10 +624,12 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
     float pg;
     if (best_yy <= best_xy) pg = 1.f;
     else pg = best_xy / (best_yy + 1);
-    __syncthreads();
-    if (lane < 3) dots[lane] = chain_dot8(x, x - (T + lane - 1), N);
-    __syncthreads();
-    float xc0 = dots[0], xc1 = dots[1], xc2 = dots[2];
+    // 3-point refinement around the selected period: xcorr[k] = <x, x-(T+k-1)> (pitch.c:511-512)
+    int cand = 0;  // which candidate won: 0 = T0, c = k-1 for T1(k)
+    for (int k = 2; k <= 15; k++)
+      if (T != T0 && T == (2 * T0 + k) / (2 * k)) { cand = k - 1; break; }
+    float xc1 = cand ? dots[2 + 2 * (cand - 1)] : dots[1];
+    float xc0 = dots[32 + 2 * cand], xc2 = dots[33 + 2 * cand];
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS + 3] = T; dbg[RN_DBG_DOTS + 4] = xc0; dbg[RN_DBG_DOTS + 5] = xc1; dbg[RN_DBG_DOTS + 6] = xc2; }
     int off2 = 0;
     if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;

@@ -76,11 +76,13 @@ struct MfmaLds {
 };
 
 // one int8 output-row tile: 6 MFMAs over K=384, A straight from the pre-swizzled weights
-__device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt, int lane, const v4i *bfrag) {
+// (B fragments are re-read from LDS per use -- conflict-free 16-byte reads -- rather than held in 48 VGPRs)
+__device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt, int lane, const int8_t *bq) {
   v4i acc = {0, 0, 0, 0};
   const v4i *a = reinterpret_cast<const v4i *>(wmf) + (size_t)rt * KT * 64 + lane;
+  const v4i *b = reinterpret_cast<const v4i *>(bq) + lane;
 #pragma unroll
-  for (int kt = 0; kt < KT; kt++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[kt * 64], bfrag[kt], acc, 0, 0, 0);
+  for (int kt = 0; kt < KT; kt++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[kt * 64], b[kt * 64], acc, 0, 0, 0);
   return acc;
 }
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ v4f int8_finish(const RnLinearDev &l, int row0, v4i a
   return o;
 }
 
-extern "C" __global__ void __launch_bounds__(NTHREADS)
+extern "C" __global__ void __launch_bounds__(NTHREADS)  // (forcing <=128 VGPRs for 4 WGs/CU spills and is slower: measured)
 rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   __shared__ __attribute__((aligned(16))) MfmaLds L;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
@@ -162,12 +164,9 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 
   // ---- conv2: int8 dense 384 -> 384, tanh; wave w owns row tiles w, w+4, ... ----
   {
-    v4i bx[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) bx[kt] = *reinterpret_cast<const v4i *>(L.xq[0] + ((kt * 64 + lane) << 4));
     for (int rt = wave; rt < 24; rt += 4) {
       const int row0 = 16 * rt + 4 * gq;
-      v4f o = int8_finish(m.conv2, row0, int8_tile(m.conv2.wmf, rt, lane, bx));
+      v4f o = int8_finish(m.conv2, row0, int8_tile(m.conv2.wmf, rt, lane, L.xq[0]));
 #pragma unroll
       for (int r = 0; r < 4; r++) o[r] = tanh_x86(o[r], lut);
       if (s0 + n < N) *reinterpret_cast<v4f *>(g.nn_act + (size_t)sn * RN_GRU + row0) = o;  // f32 copy for dense_out
@@ -186,20 +185,14 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     }
     __syncthreads();
     const RnLinearDev &wi = m.gru_in[k], &wr = m.gru_rec[k];
-    v4i bx[KT], bh[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt++) {
-      bx[kt] = *reinterpret_cast<const v4i *>(L.xq[cur] + ((kt * 64 + lane) << 4));
-      bh[kt] = *reinterpret_cast<const v4i *>(L.hq + ((kt * 64 + lane) << 4));
-    }
     for (int u = wave; u < 24; u += 4) {
       const int unit0 = 16 * u + 4 * gq;
       const v4f h_old = *reinterpret_cast<const v4f *>(st + (size_t)sn * RN_GRU + unit0);
       v4f gi[3], gr[3];
 #pragma unroll
       for (int gate = 0; gate < 3; gate++) {
-        gi[gate] = int8_finish(wi, gate * RN_GRU + unit0, int8_tile(wi.wmf, gate * 24 + u, lane, bx));
-        gr[gate] = int8_finish(wr, gate * RN_GRU + unit0, int8_tile(wr.wmf, gate * 24 + u, lane, bh));
+        gi[gate] = int8_finish(wi, gate * RN_GRU + unit0, int8_tile(wi.wmf, gate * 24 + u, lane, L.xq[cur]));
+        gr[gate] = int8_finish(wr, gate * RN_GRU + unit0, int8_tile(wr.wmf, gate * 24 + u, lane, L.hq));
         const v4f dg = *reinterpret_cast<const v4f *>(wr.diag + gate * RN_GRU + unit0);
 #pragma unroll
         for (int r = 0; r < 4; r++) gr[gate][r] += dg[r] * h_old[r];  // src/nnet_arch.h:153-161
