@@ -38,7 +38,9 @@ FRAME = 480
 
 # algorithmic HBM bytes per stream-frame of each kernel (DESIGN.md "kernels"); W is added to
 # the network kernel at run time from the model
-ANALYSIS_BYTES = 1920 + 4992 + 6912 + 3848 + 3848 + 384 + 260 + 8 + 8 + 12
+# analysis = K0 (in 1920 r, ring slot 1920 w, hp state 16) + K1 (ring: 6912 downsample + 2 x 3840 windows r,
+# X re-read 3200 r; X,P 7696 + E 384 + features 260 + flags 12 w)
+ANALYSIS_BYTES = (1920 + 1920 + 16) + (6912 + 3840 + 3840 + 3200) + (7696 + 384 + 260 + 12)
 SYNTHESIS_BYTES = 3848 + 3848 + 384 + 128 + 128 + 256 + 1920 + 1920 + 1920
 NETWORK_STATE_BYTES = 260 + 2 * (520 + 1024 + 4608) + 128 + 4
 
@@ -71,6 +73,21 @@ def synth_pcm_torch(torch, n_streams: int, n_frames: int, device, seed_base: int
         x = torch.clamp(torch.round(6000.0 * h + 1500.0 * nz), -32768, 32767)
         out[:, s0:s0 + chunk] = x.reshape(ids.shape[0], n_frames, FRAME).permute(1, 0, 2)
     return out
+
+
+def measured_traffic(kernel: str, n_streams: int):
+    """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction), scaled to this batch size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        if kernel == "rn_analysis_kernel":
+            per = k["rn_analysis_kernel"]["hbm_bytes_per_frame"] + k["rn_hp_kernel"]["hbm_bytes_per_frame"]
+        else:
+            per = k[kernel]["hbm_bytes_per_frame"]
+        return int(per * n_streams)
+    except Exception:
+        return None
 
 
 def cpu_baseline(blob: bytes):
@@ -195,6 +212,7 @@ def main():
         per_kernel = {"analysis": ANALYSIS_BYTES, "network": W + NETWORK_STATE_BYTES, "synthesis": SYNTHESIS_BYTES}
         dom = max(("analysis", "network", "synthesis"), key=lambda k: kms[k])
         ach = per_kernel[dom] * N / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        kname = f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel"
         line = {
             "metric": "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": a.gpus, "steps": K, "warmup": Wm,
@@ -206,9 +224,9 @@ def main():
                                    f"exporter-made model, network path = {a.nn}",
                        "streams_per_gpu": N, "frames_per_step": N * a.gpus, "nn_path": a.nn,
                        "outputs_sane": sane},
-            "roofline": {"bound": "hbm", "kernel": f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel",
+            "roofline": {"bound": "hbm", "kernel": kname + (" (+rn_hp_kernel)" if dom == "analysis" else ""),
                          "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": measured_traffic(kname, N),
                          "algorithmic_bytes_per_launch": per_kernel[dom] * N,
                          "kernel_ms": {k: round(kms[k], 4) for k in ("analysis", "network", "synthesis")}},
             "weight_roofline": {"W_bytes_per_frame": W, "frac": round(value * W / (a.gpus * HBM_PEAK), 5),
