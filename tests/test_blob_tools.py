@@ -1,0 +1,71 @@
+"""Blob tooling: rnnoise_amd/blob.py reads/writes the reference's "DNNw" format and
+synthesises default-architecture models that the oracle, the library and (where built) the
+reference itself all accept."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from oracle.binding import Oracle, RefHarness
+from rnnoise_amd import blob as rb
+from rnnoise_amd import capi, synth
+
+
+def test_read_write_round_trip_is_byte_identical(blob_default, blob_little):
+    for b in (blob_default, blob_little):
+        rec = rb.read_blob(b)
+        assert len(rec) == 43 and list(rec)[0] == "conv1_weights_float"
+        assert rb.write_blob(rec) == b  # the reference writer's exact bytes (src/write_weights.c:46-69)
+
+
+def test_malformed_streams_raise():
+    with pytest.raises(ValueError):
+        rb.read_blob(b"\0" * 63)
+    with pytest.raises(ValueError):
+        rb.read_blob(b"DNNw" + b"\0" * 60)  # size 0
+
+
+@pytest.mark.parametrize("density", [0.1, 1 / 3, 1.0])
+def test_synthetic_models_are_accepted_and_behave(density):
+    b = rb.synth_model(seed=7, density=density)
+    rec = rb.read_blob(b)
+    assert len(rec) == 43
+    nb = rec["gru2_input_weights_int8"].size // 32
+    assert abs(nb / (144 * 96) - density) < 0.02
+    m = capi.Model(b)  # library-side parser + weight-byte accounting (no GPU needed)
+    blocks = sum(rec[f"gru{k}_{side}_weights_int8"].size // 32 for k in (1, 2, 3) for side in ("input", "recurrent"))
+    expect_w = 303236 + 150528 + 32 * blocks + 4 * (blocks + 6 * 144) + 6 * 9216 + 3 * 4608  # SURVEY 8d formula
+    assert m.weight_bytes == expect_w
+    pcm = synth.stream_pcm(1, 40).astype(np.float32).reshape(40, 480)
+    res = Oracle(b).run(pcm)
+    assert np.isfinite(res["out"]).all() and res["gains"].std() > 0.05
+    if RefHarness.available():  # the reference's own parser and kernels agree with the oracle on it
+        ref = RefHarness(b).run(pcm)
+        for k in ("out", "gains", "vad", "pitch"):
+            assert_bits_equal(res[k], ref[k], k)
+
+
+def test_cli_info(tmp_path, capsys, blob_default):
+    p = tmp_path / "m.blob"
+    p.write_bytes(blob_default)
+    rb.main(["info", str(p)])
+    out = capsys.readouterr().out
+    assert "43 records" in out and "gru3_recurrent" in out and "density 0.33" in out
+    rb.main(["synth", str(tmp_path / "s.blob"), "--seed", "3", "--density", "0.2"])
+    assert len(rb.read_blob((tmp_path / "s.blob").read_bytes())) == 43
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density,path", [(1.0, 1), (1.0, 0), (0.1, 1)])
+def test_synthetic_models_on_gpu(density, path):
+    """dense (largest index lists, SURVEY config stress) and very sparse models, both network paths"""
+    b = rb.synth_model(seed=11, density=density)
+    m = capi.Model(b)
+    pcm = synth.batch_pcm([0, 5, 9], 30, lead_silence=2)
+    batch = capi.Batch(m, 3)
+    batch.set_nn_path(path)
+    out, vad, gains = batch.process(pcm)
+    for i in range(3):
+        want = Oracle(b).run(pcm[:, i])
+        assert_bits_equal(gains[:, i], want["gains"], "gains")
+        assert_bits_equal(vad[:, i], want["vad"], "vad")
+        assert_bits_equal(out[:, i], want["out"], "pcm")
