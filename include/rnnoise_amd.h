@@ -63,6 +63,23 @@ RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);
  * fraction reported by bench.py. */
 RNNOISE_EXPORT long rnnoise_model_weight_bytes(RNNModel *model);
 
+/* Training-feature extraction (the inner loop of the reference's src/dump_features.c:466-491, a
+ * TRAINING=1 build of denoise.c): per frame and stream, Ey from the CLEAN frame, the 65 features
+ * from the NOISY frame (no silence short-cut), the 32 band-gain targets and the VAD target passed
+ * through: records[n_frames][n_streams][98] = features | gains | vad.  Mixing, filtering and
+ * augmentation of the signals stay with the caller, as in dump_features.  lowpass[n_streams] is the
+ * first zeroed FFT bin (481 = none, src/denoise.c:340-343), band_lp[n_streams] the last band with a
+ * valid target (32 = all), noise_free[n_streams] = (noise_gain==0 && fgnoise_gain==0).
+ * The batch's per-stream analysis state tracks the noisy signal; a batch used for extraction
+ * should not be mixed with rnnoise_batch_process calls.  Host-buffer and device-buffer variants. */
+RNNOISE_EXPORT int rnnoise_batch_train_features(RNNoiseBatch *b, float *records, const float *clean,
+                                                const float *noisy, const float *vad, const int *lowpass,
+                                                const int *band_lp, const int *noise_free, int n_frames);
+RNNOISE_EXPORT int rnnoise_batch_train_features_device(RNNoiseBatch *b, float *d_records, const float *d_clean,
+                                                       const float *d_noisy, const float *d_vad, const int *d_lowpass,
+                                                       const int *d_band_lp, const int *d_noise_free, int n_frames,
+                                                       void *hip_stream);
+
 /* Test taps for the last processed frame step: per-stream feature vectors [N][65],
  * silence flags [N] and final pitch periods [N] (host buffers, any may be NULL). */
 RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch);

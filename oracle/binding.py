@@ -92,6 +92,7 @@ class Oracle(_FrameRunner):
             L.rno_pitch.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float)]
             L.rno_pitch_debug.restype = C.c_float
             L.rno_pitch_debug.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+            L.rno_train_frame.argtypes = [C.POINTER(C.c_float)] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
             L.rno_compute_rnn.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
             L.rno_band_energy.argtypes = [C.POINTER(C.c_float)] * 2
             L.rno_interp_band_gain.argtypes = [C.POINTER(C.c_float)] * 2
@@ -243,3 +244,50 @@ class RefHarness(_FrameRunner):
         lp = np.zeros(864, np.float32)
         g = cls.lib().refh_pitch(_fp(buf), last_period, last_gain, C.byref(T), _fp(lp))
         return T.value, g, lp
+
+
+class TrainOracle:
+    """oracle side of the training-feature extraction step (rno_train_frame)"""
+
+    def __init__(self):
+        self.L = Oracle.lib()
+        self.state = np.zeros(STATE_FLOATS, np.float32)
+        self.clean_mem = np.zeros(FRAME, np.float32)
+
+    def frame(self, clean, noisy, lowpass=481, band_lp=32, vad=0.0, noise_free=0):
+        clean = np.ascontiguousarray(clean, np.float32)
+        noisy = np.ascontiguousarray(noisy, np.float32)
+        rec = np.zeros(98, np.float32)
+        self.L.rno_train_frame(_fp(self.state), _fp(self.clean_mem), _fp(clean), _fp(noisy), lowpass, band_lp, vad,
+                               noise_free, _fp(rec))
+        return rec
+
+
+class RefTrainHarness:
+    """the reference's own TRAINING=1 functions (oracle/ref_harness_train.c)"""
+    PATH = os.path.join(HERE, "_ref", "libref_harness_train.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        L = C.CDLL(self.PATH)
+        L.refht_create.restype = C.c_void_p
+        L.refht_destroy.argtypes = [C.c_void_p]
+        L.refht_frame.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float,
+                                  C.c_int, C.POINTER(C.c_float)]
+        self.L = L
+        self.h = L.refht_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.refht_destroy(self.h)
+            self.h = None
+
+    def frame(self, clean, noisy, lowpass=481, band_lp=32, vad=0.0, noise_free=0):
+        clean = np.ascontiguousarray(clean, np.float32)
+        noisy = np.ascontiguousarray(noisy, np.float32)
+        rec = np.zeros(98, np.float32)
+        self.L.refht_frame(self.h, _fp(clean), _fp(noisy), lowpass, band_lp, vad, noise_free, _fp(rec))
+        return rec

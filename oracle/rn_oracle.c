@@ -848,28 +848,29 @@ static void pitch_filter(cpx *X, const cpx *P, const float *Ex, const float *Ep,
 
 void rno_state_init(float *st) { memset(st, 0, RN_STATE_FLOATS * sizeof(float)); }
 
-float rno_process_frame(const RnoModel *m, float *st, float *out, const float *in, RnoRecord *rec) {
-  cpx X[NFREQ], P[NFREQ];
-  float x[NFRAME], xw[NWIN], p[NWIN], lp[RN_PITCH_BUF_SIZE >> 1];
-  float Ex[NB], Ep[NB], Exp[NB], Ly[NB], features[RN_NB_FEATURES], g[NB], gf[NFREQ];
-  float vad_prob = 0, E = 0, gain, follow, logMax;
-  float *pitch_buf = st + RN_OFF_PITCH_BUF;
-  cpx *dX = (cpx *)(st + RN_OFF_DELAYED_X);
-  int i, pitch_index, last_period, silence;
-  tables_init();
-  if (rec) memset(rec, 0, sizeof *rec);
-
-  biquad_hp(x, st + RN_OFF_MEM_HP, in);
-
-  /* rnn_frame_analysis, denoise.c:332-345 */
-  memcpy(xw, st + RN_OFF_ANALYSIS, NFRAME * sizeof(float));
-  memcpy(xw + NFRAME, x, NFRAME * sizeof(float));
-  memcpy(st + RN_OFF_ANALYSIS, x, NFRAME * sizeof(float));
+/* rnn_frame_analysis (src/denoise.c:332-345) on an explicit 480-sample analysis memory.
+   lowpass < NFREQ applies the TRAINING-mode band limit (denoise.c:340-343). */
+static void frame_analysis(float *analysis_mem, cpx *X, float *Ex, const float *in, int lowpass) {
+  float xw[NWIN];
+  int i;
+  memcpy(xw, analysis_mem, NFRAME * sizeof(float));
+  memcpy(xw + NFRAME, in, NFRAME * sizeof(float));
+  memcpy(analysis_mem, in, NFRAME * sizeof(float));
   apply_window(xw);
   forward_transform(X, xw);
+  for (i = lowpass; i < NFREQ; i++) X[i].r = X[i].i = 0;
   compute_band_energy(Ex, X);
+}
 
-  /* rnn_compute_frame_features, denoise.c:359-398 */
+/* rnn_compute_frame_features (src/denoise.c:347-398) on the flat state; `training` selects the
+   TRAINING=1 build semantics (no silence short-cut; return value E < 0.1, denoise.c:389,397). */
+static int frame_features(float *st, cpx *X, cpx *P, float *Ex, float *Ep, float *Exp, float *features,
+                          const float *x, int training, int lowpass, int *pitch_out, float *gain_out) {
+  float p[NWIN], lp[RN_PITCH_BUF_SIZE >> 1], Ly[NB];
+  float E = 0, gain, follow, logMax;
+  float *pitch_buf = st + RN_OFF_PITCH_BUF;
+  int i, pitch_index, last_period;
+  frame_analysis(st + RN_OFF_ANALYSIS, X, Ex, x, lowpass);
   memmove(pitch_buf, pitch_buf + NFRAME, (RN_PITCH_BUF_SIZE - NFRAME) * sizeof(float));
   memcpy(pitch_buf + RN_PITCH_BUF_SIZE - NFRAME, x, NFRAME * sizeof(float));
   pitch_downsample(pitch_buf, lp);
@@ -898,15 +899,53 @@ float rno_process_frame(const RnoModel *m, float *st, float *out, const float *i
     follow = (float)((follow - 1.5 > Ly[i]) ? follow - 1.5 : Ly[i]);
     E += Ex[i];
   }
-  if (E < 0.04) {
-    memset(features, 0, sizeof features);
-    silence = 1;
-  } else {
-    dct(features, Ly);
-    features[0] -= 12;
-    features[1] -= 4;
-    silence = 0;
+  *pitch_out = pitch_index;
+  *gain_out = gain;
+  if (!training && E < 0.04) {
+    memset(features, 0, RN_NB_FEATURES * sizeof(float));
+    return 1;
   }
+  dct(features, Ly);
+  features[0] -= 12;
+  features[1] -= 4;
+  return training && E < 0.1;
+}
+
+/* One step of the training-feature extraction loop (src/dump_features.c:466-491, a TRAINING=1
+   build): Ey from the clean frame, features from the noisy frame, band-gain targets, VAD passed
+   through.  rec98 = features[65] | g[32] | vad.  `noise_free` = (noise_gain==0 && fgnoise_gain==0). */
+void rno_train_frame(float *st_noisy, float *clean_analysis_mem, const float *clean, const float *noisy, int lowpass,
+                     int band_lp, float vad_target, int noise_free, float *rec98) {
+  cpx X[NFREQ], P[NFREQ], Y[NFREQ];
+  float Ex[NB], Ep[NB], Exp[NB], Ey[NB];
+  float pg;
+  int i, pitch, silence;
+  tables_init();
+  frame_analysis(clean_analysis_mem, Y, Ey, clean, lowpass);
+  silence = frame_features(st_noisy, X, P, Ex, Ep, Exp, rec98, noisy, 1, lowpass, &pitch, &pg);
+  for (i = 0; i < NB; i++) { /* dump_features.c:472-478 */
+    float g = (float)sqrt((Ey[i] + 1e-3) / (Ex[i] + 1e-3));
+    if (g > 1) g = 1;
+    if (silence || i > band_lp) g = -1;
+    if (Ey[i] < 5e-2 && Ex[i] < 5e-2) g = -1;
+    if (vad_target == 0 && noise_free) g = -1;
+    rec98[RN_NB_FEATURES + i] = g;
+  }
+  rec98[RN_NB_FEATURES + NB] = vad_target;
+}
+
+float rno_process_frame(const RnoModel *m, float *st, float *out, const float *in, RnoRecord *rec) {
+  cpx X[NFREQ], P[NFREQ];
+  float x[NFRAME], xw[NWIN];
+  float Ex[NB], Ep[NB], Exp[NB], features[RN_NB_FEATURES], g[NB], gf[NFREQ];
+  float vad_prob = 0, gain;
+  cpx *dX = (cpx *)(st + RN_OFF_DELAYED_X);
+  int i, pitch_index, silence;
+  tables_init();
+  if (rec) memset(rec, 0, sizeof *rec);
+
+  biquad_hp(x, st + RN_OFF_MEM_HP, in);
+  silence = frame_features(st, X, P, Ex, Ep, Exp, features, x, 0, NFREQ, &pitch_index, &gain);
   if (rec) {
     rec->pitch = pitch_index;
     rec->pitch_gain = gain;

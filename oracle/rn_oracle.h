@@ -39,6 +39,10 @@ void rno_model_free(RnoModel *m);
 void rno_state_init(float *state /* RN_STATE_FLOATS */);
 float rno_process_frame(const RnoModel *m, float *state, float *out, const float *in, RnoRecord *rec);
 
+/* training-feature extraction step (src/dump_features.c:466-491 with TRAINING=1 semantics) */
+void rno_train_frame(float *st_noisy, float *clean_analysis_mem480, const float *clean, const float *noisy, int lowpass,
+                     int band_lp, float vad_target, int noise_free, float *rec98);
+
 /* stage-level entry points for known-answer tests */
 void rno_fft(const float *in_ri, float *out_ri); /* 960 interleaved complex */
 void rno_tables(float *half_window480, float *dct1024, float *twiddles1920, int *bitrev960);

@@ -32,6 +32,7 @@ EXPORTS = [
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device",
 ]
 
 
@@ -87,6 +88,8 @@ def lib():
         L.rnnoise_model_weight_bytes.argtypes = [vp]
         L.rnnoise_batch_debug_last.argtypes = [vp, fp, ip, ip]
         L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
+        L.rnnoise_batch_train_features.argtypes = [vp, fp, fp, fp, fp, ip, ip, ip, C.c_int]
+        L.rnnoise_batch_train_features_device.argtypes = [vp] * 8 + [C.c_int, vp]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         _lib = L
@@ -187,6 +190,20 @@ class Batch:
         if lib().rnnoise_batch_debug_last(self.h, _fp(f), s.ctypes.data_as(ip), p.ctypes.data_as(ip)):
             raise RuntimeError("debug_last failed")
         return f, s, p
+
+    def train_features(self, clean, noisy, vad, lowpass, band_lp, noise_free):
+        """clean/noisy: (T, N, 480); vad: (T, N); lowpass/band_lp/noise_free: (N,) ints -> records (T, N, 98)."""
+        clean = np.ascontiguousarray(clean, np.float32)
+        noisy = np.ascontiguousarray(noisy, np.float32)
+        vad = np.ascontiguousarray(vad, np.float32)
+        T, N, _ = clean.shape
+        ia = [np.ascontiguousarray(a, np.int32) for a in (lowpass, band_lp, noise_free)]
+        rec = np.empty((T, N, 98), np.float32)
+        ip = C.POINTER(C.c_int)
+        if lib().rnnoise_batch_train_features(self.h, _fp(rec), _fp(clean), _fp(noisy), _fp(vad),
+                                              *[a.ctypes.data_as(ip) for a in ia], T):
+            raise RuntimeError("rnnoise_batch_train_features failed")
+        return rec
 
     def debug_pitch(self, arm_only: bool = False):
         if arm_only:

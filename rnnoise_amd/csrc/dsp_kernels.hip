@@ -352,8 +352,9 @@ struct AnalysisLds {
 // into the pitch ring.  grid = n_streams blocks of one wavefront; ~12 KB of LDS per wave.
 // `ring0` = physical ring position of pitch_buf[0] (src/denoise.c:359-360 shift = ring rotation).
 // ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(WAVE)
-rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
+template <bool TRAIN>
+__device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int ring0, int parity,
+                                              const RnTrainArgs &tr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x;
@@ -374,6 +375,10 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
     L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
   fft960_lds(L.F, tw, lane);
+  if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) L.F[i] = {0.f, 0.f};
+    __syncthreads();
+  }
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
     cpx v = L.F[i];
@@ -695,20 +700,76 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
     }
   }
   __syncthreads();
-  const int silence = ((double)E < 0.04) ? 1 : 0;
+  // inference: silent frames zero the features and skip the network (src/denoise.c:389-393);
+  // TRAINING build: features are always produced and "silence" means E < 0.1 (:389,:397)
+  const int silence = TRAIN ? (((double)E < 0.1) ? 1 : 0) : (((double)E < 0.04) ? 1 : 0);
+  const bool zero = !TRAIN && silence;
   if (lane < RN_NB_BANDS) {
     float f_lo = dct_lane(Ly, lane, tb);
     if (lane == 0) f_lo -= 12;
     if (lane == 1) f_lo -= 4;
-    feat[lane] = silence ? 0.f : f_lo;
-    feat[RN_NB_BANDS + lane] = silence ? 0.f : f_hi;
+    feat[lane] = zero ? 0.f : f_lo;
+    feat[RN_NB_BANDS + lane] = zero ? 0.f : f_hi;
+    if (TRAIN) {
+      tr.rec[(size_t)s * 98 + lane] = f_lo;
+      tr.rec[(size_t)s * 98 + RN_NB_BANDS + lane] = f_hi;
+    }
   }
   if (lane == 0) {
-    feat[2 * RN_NB_BANDS] = silence ? 0.f : (float)(.01 * (double)(pitch_index - 300));
+    const float fp = (float)(.01 * (double)(pitch_index - 300));
+    feat[2 * RN_NB_BANDS] = zero ? 0.f : fp;
+    if (TRAIN) tr.rec[(size_t)s * 98 + 2 * RN_NB_BANDS] = fp;
     g.silence[s] = silence;
+  }
+  if (TRAIN) {
+    // rnn_frame_analysis of the CLEAN frame (src/dump_features.c:468) and the band-gain targets (:472-478)
+    __syncthreads();
+    float *cm = tr.clean_mem + (size_t)s * RN_FRAME_SIZE;
+    const float *cx = tr.clean + (size_t)s * RN_FRAME_SIZE;
+    for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+      float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
+      float v = (i < RN_FRAME_SIZE ? cm[i] : cx[i - RN_FRAME_SIZE]) * w;
+      L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+    }
+    fft960_lds(L.F, tw, lane);
+    for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) cm[i] = cx[i];
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) L.F[i] = {0.f, 0.f};
+    __syncthreads();
+    float *Ey = Ep;  // Ep already went to HBM
+    band_accumulate(Ey, L.F, L.F, L.xlp, sums, tb, lane);
+    if (lane < RN_NB_BANDS) {
+      float gt = (float)sqrt(((double)Ey[lane] + 1e-3) / ((double)Ex[lane] + 1e-3));
+      if (gt > 1) gt = 1;
+      if (silence || lane > tr.band_lp[s]) gt = -1;
+      if ((double)Ey[lane] < 5e-2 && (double)Ex[lane] < 5e-2) gt = -1;
+      const float vt = tr.vad[s];
+      if (vt == 0 && tr.noise_free[s]) gt = -1;
+      tr.rec[(size_t)s * 98 + RN_NB_FEATURES + lane] = gt;
+      if (lane == 0) tr.rec[(size_t)s * 98 + 97] = vt;
+    }
   }
   CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
 #undef PB
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
+  analysis_body<false>(g, tb, ring0, parity, RnTrainArgs{});
+}
+
+// TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity, RnTrainArgs tr) {
+  analysis_body<true>(g, tb, ring0, parity, tr);
+}
+
+// the noisy training frame enters the pitch ring unfiltered (dump_features filters while mixing)
+extern "C" __global__ void __launch_bounds__(128)
+rn_ring_store_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  if (t < RN_FRAME_SIZE / 4)
+    reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE)[t] =
+        reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE)[t];
 }
 
 struct SynthLds {
@@ -816,6 +877,14 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
   hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot);
   const int ring0 = (((slot + 1) % RN_RING_SLOTS) * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
   hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, ring0, parity);
+  return hipGetLastError();
+}
+extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
+                                               int parity, const RnTrainArgs *tr, hipStream_t st) {
+  hipLaunchKernelGGL(rn_ring_store_kernel, dim3(g->n_streams), dim3(128), 0, st, *g, noisy, slot);
+  const int ring0 = (((slot + 1) % RN_RING_SLOTS) * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
+  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, ring0,
+                     parity, *tr);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int parity,

@@ -70,5 +70,17 @@ struct RnGroupDev {
   float *gains;        // [N][32] raw network gains of the current step
   float *vad;          // [N]
   float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)
+  float *train_clean_mem;  // [N][480] analysis memory of the clean stream (training-feature extraction only)
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
+};
+
+// per-step arguments of the training-feature extraction kernel (src/dump_features.c:466-491)
+struct RnTrainArgs {
+  const float *clean;      // [N][480] clean target frames (already filtered/scaled by the caller's mixer)
+  float *clean_mem;        // [N][480] analysis memory of the clean stream (the `st` state of dump_features)
+  const float *vad;        // [N] VAD targets, passed through to the record
+  const int *lowpass;      // [N] first zeroed bin (denoise.c:340-343); 481 = none
+  const int *band_lp;      // [N] bands above this get target -1 (dump_features.c:475); 32 = none
+  const int *noise_free;   // [N] noise_gain==0 && fgnoise_gain==0 (dump_features.c:477)
+  float *rec;              // [N][98] out: features[65] | gain targets[32] | vad
 };

@@ -20,6 +20,8 @@
 
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, const float *, int, int, hipStream_t);
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_train_features(const RnGroupDev *, const RnTablesDev *, const float *, int, int,
+                                               const RnTrainArgs *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
@@ -455,6 +457,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
   g.nn_act = carve<float>(p, RN_GRU * N);
+  g.train_clean_mem = carve<float>(p, RN_FRAME_SIZE * N);
   return (size_t)(p - base);
 }
 
@@ -628,6 +631,60 @@ extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *i
   if (vad) HIP_OK(hipMemcpy(vad, b->stage_vad, n_frames * N * 4, hipMemcpyDeviceToHost));
   if (gains) HIP_OK(hipMemcpy(gains, b->stage_gains, n_frames * N * RN_NB_BANDS * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+// ---- training-feature extraction (reference loop src/dump_features.c:466-491) ----
+extern "C" int rnnoise_batch_train_features_device(RNNoiseBatch *b, float *d_records, const float *d_clean,
+                                                   const float *d_noisy, const float *d_vad, const int *d_lowpass,
+                                                   const int *d_band_lp, const int *d_noise_free, int n_frames,
+                                                   void *hip_stream) {
+  if (!b || !d_records || !d_clean || !d_noisy || !d_vad || !d_lowpass || !d_band_lp || !d_noise_free || n_frames < 0)
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  HIP_OK(hipSetDevice(b->device));
+  const size_t N = b->n;
+  for (int f = 0; f < n_frames; f++) {
+    RnTrainArgs tr;
+    tr.clean = d_clean + f * N * RN_FRAME_SIZE;
+    tr.clean_mem = b->g.train_clean_mem;
+    tr.vad = d_vad + f * N;
+    tr.lowpass = d_lowpass;
+    tr.band_lp = d_band_lp;
+    tr.noise_free = d_noise_free;
+    tr.rec = d_records + f * N * 98;
+    HIP_OK(rn_launch_train_features(&b->g, &b->tb, d_noisy + f * N * RN_FRAME_SIZE, b->ring_slot, b->parity, &tr, st));
+    b->parity ^= 1;
+    b->ring_slot = (b->ring_slot + 1) % RN_RING_SLOTS;
+  }
+  return 0;
+}
+
+extern "C" int rnnoise_batch_train_features(RNNoiseBatch *b, float *records, const float *clean, const float *noisy,
+                                            const float *vad, const int *lowpass, const int *band_lp,
+                                            const int *noise_free, int n_frames) {
+  if (!b || !records || !clean || !noisy || !vad || !lowpass || !band_lp || !noise_free || n_frames <= 0) return -1;
+  HIP_OK(hipSetDevice(b->device));
+  const size_t N = b->n, fb = (size_t)n_frames * N * RN_FRAME_SIZE * 4;
+  char *dev = nullptr;
+  const size_t o_clean = 0, o_noisy = fb, o_vad = 2 * fb, o_rec = o_vad + (size_t)n_frames * N * 4,
+               o_lp = o_rec + (size_t)n_frames * N * 98 * 4, o_bl = o_lp + N * 4, o_nf = o_bl + N * 4, total = o_nf + N * 4;
+  HIP_OK(hipMalloc((void **)&dev, total));
+  int rc = -1;
+  if (hipMemcpy(dev + o_clean, clean, fb, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dev + o_noisy, noisy, fb, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dev + o_vad, vad, (size_t)n_frames * N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dev + o_lp, lowpass, N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dev + o_bl, band_lp, N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dev + o_nf, noise_free, N * 4, hipMemcpyHostToDevice) == hipSuccess &&
+      rnnoise_batch_train_features_device(b, (float *)(dev + o_rec), (const float *)(dev + o_clean),
+                                          (const float *)(dev + o_noisy), (const float *)(dev + o_vad),
+                                          (const int *)(dev + o_lp), (const int *)(dev + o_bl), (const int *)(dev + o_nf),
+                                          n_frames, nullptr) == 0 &&
+      hipDeviceSynchronize() == hipSuccess &&
+      hipMemcpy(records, dev + o_rec, (size_t)n_frames * N * 98 * 4, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = 0;
+  hipFree(dev);
+  return rc;
 }
 
 #define D2H(dst, src, count) HIP_OK(hipMemcpy(dst, src, (count) * 4, hipMemcpyDeviceToHost))
