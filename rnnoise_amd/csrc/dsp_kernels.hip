@@ -333,19 +333,24 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
   return s;
 }
 
+// One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared:
+//   FFT phases   : F = floats [0,1920) (960 complex); the band products Q live in [1000,1864), above
+//                  the 481 bins that matter; small per-frame vectors in [2392,2560)
+//   pitch phase  : xlp [0,864) | squares [864,1728) (4x-decimated copy y4 in its upper part during
+//                  the coarse search) | running energies [1728,2024) | xcorr [2024,2320); yy_lookup
+//                  and the dot products reuse [1728,2184) once the searches are done
 struct AnalysisLds {
-  cpx F[RN_WINDOW_SIZE];        // FFT work area; scratch for the pitch analysis in between
-  float xlp[864];               // 2x decimated, LPC-whitened (src/pitch.c:146-214); band-product scratch
-  float sums[40];               // band accumulators (34 used)
-  float Ex[RN_NB_BANDS], Ep[RN_NB_BANDS], Exp[RN_NB_BANDS], Ly[RN_NB_BANDS];
+  float a[2560];
 };
-// float offsets inside the idle FFT area during the pitch analysis
-#define SCR_SQ 0      // [864]  squares of y4 / xlp
-#define SCR_SYY 864   // [296]  running energies of find_best_pitch
-#define SCR_YYL 1163  // [385]  yy_lookup; index i lives at SCR_YYL+i so that i = 4m+1 is 16-byte aligned
-#define SCR_DOTS 1552 // [64]  (overlaps the tail of y4, which is dead by then)
-#define SCR_Y4 1164   // [432]  4x-decimated signal, dead before yy_lookup/dots are written
-#define SCR_XC 1620   // [296]  xcorr[] of pitch_search
+#define SCR_XLP 0
+#define SCR_SQ 864    // [864]  squares of y4 / xlp
+#define SCR_Y4 1296   // [432]  4x-decimated signal (coarse search only; squares need [864,1252) then)
+#define SCR_SYY 1728  // [296]  running energies of find_best_pitch
+#define SCR_XC 2024   // [296]  xcorr[] of pitch_search
+#define SCR_YYL 1731  // [385]  yy_lookup; index i lives at SCR_YYL+i so that i = 4m+1 is 16-byte aligned
+#define SCR_DOTS 2120 // [64]
+#define SCR_Q 1000    // [864]  band products
+#define SCR_MISC 2392 // sums[40] | Ex[32] | Ep[32] | Exp[32] | Ly[32]
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
@@ -359,8 +364,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x;
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
-  float *Ex = L.Ex, *Ep = L.Ep, *Exp = L.Exp, *Ly = L.Ly, *sums = L.sums;
-  float *scr = reinterpret_cast<float *>(L.F);
+  float *scr = L.a;
+  cpx *F = reinterpret_cast<cpx *>(L.a);
+  float *xlp = scr + SCR_XLP, *Qs = scr + SCR_Q;
+  float *sums = scr + SCR_MISC, *Ex = sums + 40, *Ep = Ex + 32, *Exp = Ep + 32, *Ly = Exp + 32;
   float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
@@ -372,20 +379,20 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
     float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i) * w;
-    L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+    F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
-  fft960_lds(L.F, tw, lane);
+  fft960_lds(F, tw, lane);
   if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) L.F[i] = {0.f, 0.f};
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[i] = {0.f, 0.f};
     __syncthreads();
   }
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = L.F[i];
+    cpx v = F[i];
     gX[2 * i] = v.r;
     gX[2 * i + 1] = v.i;
   }
-  band_accumulate(Ex, L.F, L.F, L.xlp, sums, tb, lane);
+  band_accumulate(Ex, F, F, Qs, sums, tb, lane);
 
   CLK_TAP(2);  // window + FFT(X) + Ex
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
@@ -393,7 +400,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     float v;
     if (i == 0) v = .5f * (.5f * (PB(1)) + PB(0));
     else v = .5f * (.5f * (PB(2 * i - 1) + PB(2 * i + 1)) + PB(2 * i));
-    L.xlp[i] = v;
+    xlp[i] = v;
   }
   __syncthreads();
   float lpc2[5];
@@ -402,9 +409,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     float ack = 0;
     if (lane < 5) {
       const int k = lane;
-      float sacc = chain_dot8(L.xlp, L.xlp + k, 856), d = 0;
-      for (int i = 856; i < 860; i++) sacc = sacc + L.xlp[i] * L.xlp[i + k];
-      for (int i = k + 860; i < 864; i++) d = d + L.xlp[i] * L.xlp[i - k];
+      float sacc = chain_dot8(xlp, xlp + k, 856), d = 0;
+      for (int i = 856; i < 860; i++) sacc = sacc + xlp[i] * xlp[i + k];
+      for (int i = k + 860; i < 864; i++) d = d + xlp[i] * xlp[i - k];
       ack = sacc + d;
     }
     float ac[5];
@@ -459,12 +466,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       int i = lane + WAVE * t;
       float sum = 0;
       if (i < 864) {
-        sum = L.xlp[i];
-        sum = sum + lpc2[0] * (i >= 1 ? L.xlp[i - 1] : 0.f);
-        sum = sum + lpc2[1] * (i >= 2 ? L.xlp[i - 2] : 0.f);
-        sum = sum + lpc2[2] * (i >= 3 ? L.xlp[i - 3] : 0.f);
-        sum = sum + lpc2[3] * (i >= 4 ? L.xlp[i - 4] : 0.f);
-        sum = sum + lpc2[4] * (i >= 5 ? L.xlp[i - 5] : 0.f);
+        sum = xlp[i];
+        sum = sum + lpc2[0] * (i >= 1 ? xlp[i - 1] : 0.f);
+        sum = sum + lpc2[1] * (i >= 2 ? xlp[i - 2] : 0.f);
+        sum = sum + lpc2[2] * (i >= 3 ? xlp[i - 3] : 0.f);
+        sum = sum + lpc2[3] * (i >= 4 ? xlp[i - 4] : 0.f);
+        sum = sum + lpc2[4] * (i >= 5 ? xlp[i - 5] : 0.f);
       }
       r[t] = sum;
     }
@@ -472,17 +479,17 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 #pragma unroll
     for (int t = 0; t < 14; t++) {
       int i = lane + WAVE * t;
-      if (i < 864) L.xlp[i] = r[t];
+      if (i < 864) xlp[i] = r[t];
     }
   }
   __syncthreads();
 
   CLK_TAP(3);  // downsample + autocorr + LPC + FIR
-  if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = L.xlp[i];
+  if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *scr_sq = scr + SCR_SQ, *scr_syy = scr + SCR_SYY;
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
-  for (int j = lane; j < 432; j += WAVE) y4[j] = L.xlp[2 * j];
+  for (int j = lane; j < 432; j += WAVE) y4[j] = xlp[2 * j];
   __syncthreads();
   for (int lag = lane; lag < 147; lag += WAVE) xc[lag] = chain_dot8(y4 + 192, y4 + lag, 240);
   __syncthreads();
@@ -500,13 +507,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   if (lane < 10) {
     int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
     if (c >= 0 && c < 294) {
-      float sum = chain_dot8(L.xlp + 384, L.xlp + c, 480);
+      float sum = chain_dot8(xlp + 384, xlp + c, 480);
       xc[c] = (-1 > sum) ? -1 : sum;
     }
   }
   __syncthreads();
   CLK_TAP(6);  // fine xcorr
-  find_best_pitch(xc, L.xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
+  find_best_pitch(xc, xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch scan
   int offset = 0;
   if (bp0 > 0 && bp0 < 293) {
@@ -525,7 +532,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   {
     const int maxperiod = 384, minperiod = 30, N = 480, minperiod0 = RN_PITCH_MIN_PERIOD;
     const int *sc = c_second_check;
-    const float *x = L.xlp + maxperiod;
+    const float *x = xlp + maxperiod;
     float *yyl = scr + SCR_YYL;
     float *dots = scr + SCR_DOTS;
     int T0 = pitch_index / 2;
@@ -564,7 +571,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     {  // yy_lookup (pitch.c:449-456): yy = (yy + x[-i]^2) - x[N-i]^2, clamped copy stored.  Squares are
        // formed by all lanes first; the recurrence is swept 8 steps per iteration with the next
        // operands already in flight.
-      for (int j = lane; j < 864; j += WAVE) scr_sq[j] = L.xlp[j] * L.xlp[j];
+      for (int j = lane; j < 864; j += WAVE) scr_sq[j] = xlp[j] * xlp[j];
       __syncthreads();
       float yy = xx;
       if (lane == 0) yyl[0] = xx;
@@ -656,18 +663,18 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
     float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i) * w;
-    L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+    F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
-  fft960_lds(L.F, tw, lane);
+  fft960_lds(F, tw, lane);
   float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = L.F[i];
+    cpx v = F[i];
     gP[2 * i] = v.r;
     gP[2 * i + 1] = v.i;
   }
-  band_accumulate(Ep, L.F, L.F, L.xlp, sums, tb, lane);
+  band_accumulate(Ep, F, F, Qs, sums, tb, lane);
   // X is read back from HBM/L2 (this block wrote it; the barriers since then make it visible)
-  band_accumulate(Exp, reinterpret_cast<const cpx *>(gX), L.F, L.xlp, sums, tb, lane);
+  band_accumulate(Exp, reinterpret_cast<const cpx *>(gX), F, Qs, sums, tb, lane);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
@@ -729,14 +736,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
       float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
       float v = (i < RN_FRAME_SIZE ? cm[i] : cx[i - RN_FRAME_SIZE]) * w;
-      L.F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
+      F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
     }
-    fft960_lds(L.F, tw, lane);
+    fft960_lds(F, tw, lane);
     for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) cm[i] = cx[i];
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) L.F[i] = {0.f, 0.f};
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[i] = {0.f, 0.f};
     __syncthreads();
     float *Ey = Ep;  // Ep already went to HBM
-    band_accumulate(Ey, L.F, L.F, L.xlp, sums, tb, lane);
+    band_accumulate(Ey, F, F, Qs, sums, tb, lane);
     if (lane < RN_NB_BANDS) {
       float gt = (float)sqrt(((double)Ey[lane] + 1e-3) / ((double)Ex[lane] + 1e-3));
       if (gt > 1) gt = 1;
