@@ -780,14 +780,42 @@ rn_ring_store_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
 }
 
 struct SynthLds {
-  cpx F[RN_WINDOW_SIZE];
-  cpx X[RN_FREQ_SIZE + 1];
+  cpx F[RN_WINDOW_SIZE];  // inverse-FFT work area; band products before that
   float misc[192];
 };
+
+// the second half of band_accumulate for callers that formed the 800 products themselves
+__device__ void band_chain_finish(float *bandE, const float *Q, float *sums, int lane) {
+  __syncthreads();
+  {
+    const int k = lane < RN_NB_BANDS + 2 ? lane : 0;
+    const int lo = k ? c_eband[k - 1] : 0;
+    const int len = lane < RN_NB_BANDS + 2 ? (k <= RN_NB_BANDS ? c_eband[k + 1] : 400) - lo : 0;
+    const float *q = Q + lo + c_eband[k];
+    float s = 0;
+#pragma unroll 4
+    for (int t = 0; t < 84; t++) {
+      const float v = q[t];
+      s += (t < len) ? v : 0.f;
+    }
+    if (lane < RN_NB_BANDS + 2) sums[lane] = s;
+  }
+  __syncthreads();
+  if (lane < RN_NB_BANDS) {
+    float v = sums[lane + 1];
+    if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
+    if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
+    bandE[lane] = v;
+  }
+  __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------------------
 // K3: rnn_pitch_filter + gain smoothing/interpolation + frame_synthesis
 // (src/denoise.c:474-496, 421-455, 140-154, 400-407, 200-217)
+// Lane l owns bins l, l+64, ..., l+448 (and bin 480 for lane 32) in registers for the whole
+// kernel; every HBM operand is requested before the first dependent instruction, so the wave
+// pays one memory round trip instead of one per stage.  8.4 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity) {
@@ -796,83 +824,122 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   const int s = blockIdx.x, lane = threadIdx.x;
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
   const int prev = parity ^ 1;
-  const float *dX = g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE;
-  const float *dP = g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE;
+  const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
+  const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
   const float *cE = g.spec_E[parity] + (size_t)s * 96;
   float *r = L.misc + 0, *gsm = L.misc + 32, *newE = L.misc + 64, *norm = L.misc + 96, *sums = L.misc + 128;
+  float *Q = reinterpret_cast<float *>(L.F);
   const int silence = g.silence[s];
+  constexpr int NBIN = 8;  // bins lane + 64*j; the 481st bin (480) is lane 32's j = 7
 
-  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) L.X[i] = {dX[2 * i], dX[2 * i + 1]};
+  // ---- every HBM operand up front ----
+  float2 X[NBIN], P[NBIN];
+  float frac[NBIN];
+  int band[NBIN];
+#pragma unroll
+  for (int j = 0; j < NBIN; j++) {
+    const int bin = lane + WAVE * j;
+    const bool ok = bin < RN_FREQ_SIZE;
+    X[j] = ok ? dX[bin] : make_float2(0.f, 0.f);
+    P[j] = (ok && !silence) ? dP[bin] : make_float2(0.f, 0.f);
+    band[j] = (bin < 400) ? tb.band_of_bin[bin] : 0;
+    frac[j] = (bin < 400) ? tb.band_frac[bin] : 0.f;
+  }
+  float e_ex = 0, e_ep = 0, e_exp = 0, c_ex = 0, gi = 0, lastg = 0;
+  if (lane < RN_NB_BANDS && !silence) {
+    e_ex = dE[lane]; e_ep = dE[32 + lane]; e_exp = dE[64 + lane]; c_ex = cE[lane];
+    gi = g.gains[(size_t)s * RN_NB_BANDS + lane];
+    lastg = g.lastg[(size_t)s * RN_NB_BANDS + lane];
+  }
+  float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
+  float smv[8], wlo[8], whi[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = lane + WAVE * j;
+    const bool ok = i < RN_FRAME_SIZE;
+    smv[j] = ok ? sm[i] : 0.f;
+    wlo[j] = ok ? tb.half_window[i] : 0.f;
+    whi[j] = ok ? tb.half_window[RN_FRAME_SIZE - 1 - i] : 0.f;
+  }
+
+// src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
+#define INTERP(vec, j)                                                                                      \
+  ((lane + WAVE * (j)) >= 400 ? 0.f                                                                         \
+   : band[j] == 0 ? (vec)[0]                                                                                \
+   : band[j] == RN_NB_BANDS ? (vec)[RN_NB_BANDS - 1]                                                        \
+                            : (1 - frac[j]) * (vec)[band[j] - 1] + frac[j] * (vec)[band[j]])
+
   if (!silence) {
-    float gi = 0;
     if (lane < RN_NB_BANDS) {  // src/denoise.c:429-440
-      const float Exp = dE[64 + lane], Ex = dE[lane], Ep = dE[32 + lane];
-      gi = g.gains[(size_t)s * RN_NB_BANDS + lane];
       float rv;
-      if (Exp > gi) rv = 1;
-      else rv = (float)((double)((Exp * Exp) * (1 - (gi * gi))) / (.001 + (double)((gi * gi) * (1 - (Exp * Exp)))));
+      if (e_exp > gi) rv = 1;
+      else rv = (float)((double)((e_exp * e_exp) * (1 - (gi * gi))) / (.001 + (double)((gi * gi) * (1 - (e_exp * e_exp)))));
       float t = (0 > rv) ? 0 : rv;
       t = (1 < t) ? 1 : t;
       rv = (float)sqrt((double)t);
-      rv = (float)((double)rv * sqrt((double)Ex / (1e-8 + (double)Ep)));
+      rv = (float)((double)rv * sqrt((double)e_ex / (1e-8 + (double)e_ep)));
       r[lane] = rv;
     }
     __syncthreads();
-    for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {  // :441-445
-      float rf = interp_gain_bin(r, i, tb);
-      cpx x = L.X[i];
-      x.r += rf * dP[2 * i];
-      x.i += rf * dP[2 * i + 1];
-      L.X[i] = x;
+#pragma unroll
+    for (int j = 0; j < NBIN; j++) {  // :441-445, then the products of compute_band_energy (:446)
+      const int bin = lane + WAVE * j;
+      const float rf = INTERP(r, j);
+      X[j].x += rf * P[j].x;
+      X[j].y += rf * P[j].y;
+      if (bin < 400) {
+        float tmp = X[j].x * X[j].x;
+        tmp += X[j].y * X[j].y;
+        Q[c_eband[band[j] + 1] + bin] = frac[j] * tmp;
+        Q[c_eband[band[j]] + bin] = (1 - frac[j]) * tmp;
+      }
     }
-    __syncthreads();
-    band_accumulate(newE, L.X, L.X, reinterpret_cast<float *>(L.F), sums, tb, lane);
+    band_chain_finish(newE, Q, sums, lane);
     if (lane < RN_NB_BANDS) {
-      norm[lane] = (float)sqrt((double)dE[lane] / (1e-8 + (double)newE[lane]));  // :447-449
-      // gain smoothing (src/denoise.c:479-487)
-      float lastg = g.lastg[(size_t)s * RN_NB_BANDS + lane];
-      const float alpha = .6f;
+      norm[lane] = (float)sqrt((double)e_ex / (1e-8 + (double)newE[lane]));  // :447-449
+      const float alpha = .6f;  // gain smoothing (src/denoise.c:479-487)
       gi = (gi > alpha * lastg) ? gi : alpha * lastg;
-      double q = (double)gi * ((double)dE[lane] + 1e-3) / ((double)cE[lane] + 1e-3);
+      double q = (double)gi * ((double)e_ex + 1e-3) / ((double)c_ex + 1e-3);
       g.lastg[(size_t)s * RN_NB_BANDS + lane] = (float)((1.f < q) ? 1.f : q);
       gsm[lane] = gi;
     }
     __syncthreads();
-    for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {  // :450-454 then :488-493
-      float nf = interp_gain_bin(norm, i, tb);
-      float gf = interp_gain_bin(gsm, i, tb);
-      cpx x = L.X[i];
-      x.r *= nf;
-      x.i *= nf;
-      x.r *= gf;
-      x.i *= gf;
-      L.X[i] = x;
+#pragma unroll
+    for (int j = 0; j < NBIN; j++) {  // :450-454 then :488-493
+      const float nf = INTERP(norm, j), gf = INTERP(gsm, j);
+      X[j].x *= nf;
+      X[j].y *= nf;
+      X[j].x *= gf;
+      X[j].y *= gf;
     }
+    __syncthreads();
   }
-  __syncthreads();
+#undef INTERP
   // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT
-  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
-    cpx v;
-    if (i < RN_FREQ_SIZE) v = L.X[i];
-    else {
-      v = L.X[RN_WINDOW_SIZE - i];
-      v.i = -v.i;
+#pragma unroll
+  for (int j = 0; j < NBIN; j++) {
+    const int bin = lane + WAVE * j;
+    if (bin < RN_FREQ_SIZE) {
+      L.F[bitrev960(bin)] = {0.0010416667f * X[j].x, 0.0010416667f * X[j].y};
+      if (bin > 0 && bin < RN_FREQ_SIZE - 1)
+        L.F[bitrev960(RN_WINDOW_SIZE - bin)] = {0.0010416667f * X[j].x, 0.0010416667f * (-X[j].y)};
     }
-    L.F[bitrev960(i)] = {0.0010416667f * v.r, 0.0010416667f * v.i};
   }
   fft960_lds(L.F, tw, lane);
   // window + overlap-add (src/denoise.c:400-407)
-  float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
   float *o = out + (size_t)s * RN_FRAME_SIZE;
-  for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) {
-    const float w = tb.half_window[i];
-    float lo = (float)RN_WINDOW_SIZE * L.F[(RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE].r;   // x[i]
-    float hi = (float)RN_WINDOW_SIZE * L.F[RN_FRAME_SIZE - i].r;                       // x[480+i], window index 479-i
-    lo *= w;
-    hi *= tb.half_window[RN_FRAME_SIZE - 1 - i];
-    o[i] = lo + sm[i];
-    sm[i] = hi;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int i = lane + WAVE * j;
+    if (i < RN_FRAME_SIZE) {
+      float lo = (float)RN_WINDOW_SIZE * L.F[(RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE].r;  // x[i]
+      float hi = (float)RN_WINDOW_SIZE * L.F[RN_FRAME_SIZE - i].r;                      // x[480+i], window index 479-i
+      lo *= wlo[j];
+      hi *= whi[j];
+      o[i] = lo + smv[j];
+      sm[i] = hi;
+    }
   }
 }
 
