@@ -62,6 +62,7 @@
 #define RN_DBG_XC_FINE 1040   /* [294] fine xcorr (src/pitch.c:344-361)                   */
 #define RN_DBG_DOTS 1340      /* xx, xy, yy, T, xcorr[3] of rnn_remove_doubling           */
 #define RN_DBG_CLK 1348       /* [12] shader-clock deltas of the analysis kernel's sections (profiling) */
-#define RN_DBG_FLOATS 1360
+#define RN_DBG_CLK2 1360      /* [16] shader-clock deltas of the MFMA network kernel phases (tile leader streams) */
+#define RN_DBG_FLOATS 1400
 
 #endif /* RN_LAYOUT_H */

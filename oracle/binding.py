@@ -163,7 +163,7 @@ class Oracle(_FrameRunner):
     def pitch_debug(cls, buf1728: np.ndarray, last_period: int, last_gain: float):
         buf = np.ascontiguousarray(buf1728, np.float32)
         T = C.c_int(0)
-        dbg = np.zeros(1360, np.float32)
+        dbg = np.zeros(1400, np.float32)
         g = cls.lib().rno_pitch_debug(_fp(buf), last_period, last_gain, C.byref(T), _fp(dbg))
         return T.value, g, dbg
 

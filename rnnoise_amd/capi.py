@@ -209,7 +209,7 @@ class Batch:
         if arm_only:
             lib().rnnoise_batch_debug_pitch(self.h, None)
             return None
-        d = np.empty((self.n, 1360), np.float32)
+        d = np.empty((self.n, 1400), np.float32)
         if lib().rnnoise_batch_debug_pitch(self.h, _fp(d)):
             raise RuntimeError("debug_pitch failed")
         return d

@@ -22,7 +22,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define TS 16          // streams per workgroup
-#define NTHREADS 256   // 4 waves
+#define NWAVES 8       // 2 waves per SIMD: one wave's weight loads / epilogue overlap the other's MFMAs
+#define NTHREADS (64 * NWAVES)
 #define KT 6           // 384 / 64 k-tiles of every int8 layer
 
 // ---- x86-profile activations (same arithmetic as nn_kernels.hip; LUT staged in LDS) ----
@@ -105,6 +106,16 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   const int sn = (s0 + n < N) ? s0 + n : N - 1;              // this lane's stream (clamped for loads)
   const bool live = (s0 + n < N) && !g.silence[sn];          // silent streams keep state (src/denoise.c:474)
   const uint32_t *lut = L.lut;
+  float *dbg = (g.debug && tid == 0) ? g.debug + (size_t)s0 * RN_DBG_FLOATS + RN_DBG_CLK2 : nullptr;
+  unsigned long long clk_prev = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+#define CLK_TAP(idx)                                           \
+  do {                                                         \
+    if (g.debug) {                                             \
+      unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+      if (dbg) dbg[idx] = (float)(now_ - clk_prev);            \
+      clk_prev = now_;                                         \
+    }                                                          \
+  } while (0)
 
   for (int i = tid; i < 2048; i += NTHREADS) L.lut[i] = tb.rcp_lut[i];
   // ---- conv1 input: [conv1_state(130) | features(65) | 0] per stream ----
@@ -116,10 +127,11 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     L.tmp1[q][k] = v;
   }
   // conv2 history: quantise old[0..255] into xq[0] (k = 0..255); keep old[128..255] to shift the state
-  v4f hist[4];
-  int hq_[4], hk_[4];
+  constexpr int HC = 1024 / NTHREADS;  // 16 streams x 64 chunks of 4 floats, spread over the workgroup
+  v4f hist[HC];
+  int hq_[HC], hk_[HC];
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
+  for (int c = 0; c < HC; c++) {
     const int chunk = tid + c * NTHREADS, q = chunk >> 6, k = (chunk & 63) << 2;  // 16 streams x 64 chunks of 4
     const int s = (s0 + q < N) ? s0 + q : N - 1;
     hist[c] = *reinterpret_cast<const v4f *>(g.conv2_state + (size_t)s * 256 + k);
@@ -134,37 +146,35 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     if (s0 + q < N && !g.silence[s0 + q]) g.conv1_state[(size_t)(s0 + q) * 130 + k] = L.tmp1[q][65 + k];
   }
 #pragma unroll
-  for (int c = 0; c < 4; c++)
+  for (int c = 0; c < HC; c++)
     if (hk_[c] >= 128 && s0 + hq_[c] < N && !g.silence[s0 + hq_[c]])
       *reinterpret_cast<v4f *>(g.conv2_state + (size_t)(s0 + hq_[c]) * 256 + hk_[c] - 128) = hist[c];
 
-  // ---- conv1: f32 MFMA, 195(+1) -> 128; wave w owns output rows 32w .. 32w+31 ----
-  {
-    v4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    const float *fw = m.conv1.fw + 32 * wave + n;
+  CLK_TAP(0);  // loads, history quantisation, state shifts
+  // ---- conv1: f32 MFMA, 195(+1) -> 128 = 8 row tiles, spread over the waves ----
+  for (int rt = wave; rt < 8; rt += NWAVES) {
+    v4f acc = {0, 0, 0, 0};
+    const float *fw = m.conv1.fw + 16 * rt + n;
     for (int j = 0; j < 49; j++) {
       const int k = 4 * j + gq;
       const float b = L.tmp1[n][k];
-      const float a0 = (k < RN_CONV1_K) ? fw[k * 128] : 0.f, a1 = (k < RN_CONV1_K) ? fw[k * 128 + 16] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+      const float a = (k < RN_CONV1_K) ? fw[k * 128] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
     }
+    const int row0 = 16 * rt + 4 * gq;
+    const v4f bs = *reinterpret_cast<const v4f *>(m.conv1.bias + row0);
+    v4f c1;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int row0 = 32 * wave + 16 * h + 4 * gq;
-      const v4f a = h ? acc1 : acc0, bs = *reinterpret_cast<const v4f *>(m.conv1.bias + row0);
-      v4f c1;
-#pragma unroll
-      for (int r = 0; r < 4; r++) c1[r] = tanh_x86(a[r] + bs[r], lut);
-      *reinterpret_cast<int *>(L.xq[0] + frag_off(n, 256 + row0)) = pack4(c1[0], c1[1], c1[2], c1[3]);
-      if (live) *reinterpret_cast<v4f *>(g.conv2_state + (size_t)sn * 256 + 128 + row0) = c1;
-    }
+    for (int r = 0; r < 4; r++) c1[r] = tanh_x86(acc[r] + bs[r], lut);
+    *reinterpret_cast<int *>(L.xq[0] + frag_off(n, 256 + row0)) = pack4(c1[0], c1[1], c1[2], c1[3]);
+    if (live) *reinterpret_cast<v4f *>(g.conv2_state + (size_t)sn * 256 + 128 + row0) = c1;
   }
   __syncthreads();
 
+  CLK_TAP(1);  // conv1
   // ---- conv2: int8 dense 384 -> 384, tanh; wave w owns row tiles w, w+4, ... ----
   {
-    for (int rt = wave; rt < 24; rt += 4) {
+    for (int rt = wave; rt < 24; rt += NWAVES) {
       const int row0 = 16 * rt + 4 * gq;
       v4f o = int8_finish(m.conv2, row0, int8_tile(m.conv2.wmf, rt, lane, L.xq[0]));
 #pragma unroll
@@ -176,6 +186,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 
   // ---- three GRUs (src/nnet.c:65-94); wave w owns hidden-unit tiles w, w+4, ... ----
   int cur = 1;
+  CLK_TAP(2);  // conv2
   for (int k = 0; k < 3; k++) {
     float *st = g.gru_state + (size_t)k * N * RN_GRU;
     for (int e = tid; e < TS * 96; e += NTHREADS) {  // quantise the old state into hq
@@ -185,7 +196,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     }
     __syncthreads();
     const RnLinearDev &wi = m.gru_in[k], &wr = m.gru_rec[k];
-    for (int u = wave; u < 24; u += 4) {
+    for (int u = wave; u < 24; u += NWAVES) {
       const int unit0 = 16 * u + 4 * gq;
       const v4f h_old = *reinterpret_cast<const v4f *>(st + (size_t)sn * RN_GRU + unit0);
       v4f gi[3], gr[3];
@@ -210,21 +221,35 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     }
     cur ^= 1;
     __syncthreads();
+    CLK_TAP(3 + k);  // GRU k
   }
 
   // ---- dense_out (1536 -> 32, f32 MFMA chains, waves 0-1) and vad_dense (wave 2, lane = stream) ----
   // cat = [conv2 out | gru1 | gru2 | gru3] (src/rnn.c:53-55); silent streams are computed on
   // their unchanged state and discarded.
+  // Both loops are dependent chains fed from L2; operands for the next 8 steps are requested
+  // before the current 8 are consumed so that the chain, not the memory latency, sets the pace.
   if (wave < 2) {
     v4f acc = {0, 0, 0, 0};
     const float *fw = m.dense_out.fw + 16 * wave + n;
-    for (int seg = 0; seg < 4; seg++) {
+    auto lda = [&](int t) { return fw[(size_t)(4 * t + gq) * RN_NB_BANDS]; };  // k = 4t + gq runs over all 1536 inputs
+    auto ldb = [&](int t) {
+      const int seg = t / 96, k = 4 * (t - 96 * seg) + gq;
       const float *src = (seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) + (size_t)sn * RN_GRU;
-      const float *fws = fw + (size_t)seg * RN_GRU * RN_NB_BANDS;
-      for (int j = 0; j < 96; j++) {
-        const int k = 4 * j + gq;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fws[k * RN_NB_BANDS], src[k], acc, 0, 0, 0);
-      }
+      return src[k];
+    };
+    float ca[8], cb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { ca[u] = lda(u); cb[u] = ldb(u); }
+    for (int t0 = 0; t0 < 384; t0 += 8) {
+      const int tn = (t0 + 8 < 384) ? t0 + 8 : t0;
+      float na[8], nb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { na[u] = lda(tn + u); nb[u] = ldb(tn + u); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u], cb[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
     }
     const int row0 = 16 * wave + 4 * gq;
     const v4f bs = *reinterpret_cast<const v4f *>(m.dense_out.bias + row0);
@@ -235,12 +260,23 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   } else if (wave == 2 && lane < TS) {
     float acc = 0;
     for (int seg = 0; seg < 4; seg++) {
-      const float *src = (seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) + (size_t)sn * RN_GRU;
-      const float *w = m.vad_dense.fw + seg * RN_GRU;
-      for (int j = 0; j < RN_GRU; j++) acc = acc + w[j] * src[j];  // unfused, src/vec_avx.h:732-736
+      const v4f *src = reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) +
+                                                     (size_t)sn * RN_GRU);
+      const v4f *w = reinterpret_cast<const v4f *>(m.vad_dense.fw + seg * RN_GRU);
+      v4f w0 = w[0], w1 = w[1], x0 = src[0], x1 = src[1];
+      for (int j = 0; j < RN_GRU / 4; j += 2) {
+        const int jn = (j + 2 < RN_GRU / 4) ? j + 2 : j;
+        const v4f nw0 = w[jn], nw1 = w[jn + 1], nx0 = src[jn], nx1 = src[jn + 1];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = acc + w0[e] * x0[e];  // unfused, src/vec_avx.h:732-736
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = acc + w1[e] * x1[e];
+        w0 = nw0; w1 = nw1; x0 = nx0; x1 = nx1;
+      }
     }
     if (s0 + n < N) g.vad[sn] = live ? sigmoid_x86(acc + m.vad_dense.bias[0], lut) : 0.f;
   }
+  CLK_TAP(6);  // dense_out / vad (wave 0's view)
 }
 
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st) {

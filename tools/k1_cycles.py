@@ -12,9 +12,15 @@ m = capi.Model(blob)
 for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
     b = capi.Batch(m, n)
     b.debug_pitch(arm_only=True)
+    b.set_nn_path(1)
     pcm = np.ascontiguousarray(np.tile(synth.batch_pcm(range(min(n, 16)), 6), (1, (n + 15) // 16, 1))[:, :n])
     b.process(pcm)
     d = b.debug_pitch()
+    if "--nn" in sys.argv:
+        clk2 = d[::16, 1360:1367]
+        print(f"--- N={n}: MFMA network kernel, mean shader clocks per phase over tiles (total {clk2.sum(1).mean():.0f}) ---")
+        for k, name in enumerate(["load+quantise", "conv1", "conv2", "gru1", "gru2", "gru3", "dense/vad"]):
+            print(f"  {name:<20} {clk2[:, k].mean():>10.0f}  {100 * clk2[:, k].mean() / clk2.sum(1).mean():5.1f}%")
     clk = d[:, 1348:1360]
     print(f"--- N={n}: mean shader clocks per section over streams (total {clk.sum(1).mean():.0f}) ---")
     for k, name in enumerate(NAMES):
