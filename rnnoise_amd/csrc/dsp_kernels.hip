@@ -944,20 +944,20 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
 }
 
 // host-visible launch helpers -----------------------------------------------------------------
-// `slot` = ring slot that receives this frame; pitch_buf[0] then sits at ring position
-// ((slot+1)*480 + 192) mod 1920 (the buffer holds the latest 1728 = 3.6 frames).
-extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, const float *in, int slot,
-                                         int parity, hipStream_t st) {
+// K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
   hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot);
-  const int ring0 = (((slot + 1) % RN_RING_SLOTS) * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
-  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, ring0, parity);
+  return hipGetLastError();
+}
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st) {
+  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, RN_RING0(slot),
+                     parity);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
                                                int parity, const RnTrainArgs *tr, hipStream_t st) {
   hipLaunchKernelGGL(rn_ring_store_kernel, dim3(g->n_streams), dim3(128), 0, st, *g, noisy, slot);
-  const int ring0 = (((slot + 1) % RN_RING_SLOTS) * RN_FRAME_SIZE + (RN_RING_SIZE - RN_PITCH_BUF_SIZE)) % RN_RING_SIZE;
-  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, ring0,
+  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, RN_RING0(slot),
                      parity, *tr);
   return hipGetLastError();
 }

@@ -16,8 +16,13 @@
 #include "../../include/rn_layout.h"
 
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
-#define RN_RING_SLOTS 4     // pitch ring: 4 frames of 480 hold the 1728-sample pitch_buf without shifting
+// pitch ring: the 1728-sample pitch_buf (3.6 frames) lives in a ring of 480-sample slots and is never
+// shifted.  Five slots rather than four, so that the high-pass kernel may already write frame t+1
+// while the analysis kernel still reads frame t's 1728 samples (they touch disjoint slots).
+#define RN_RING_SLOTS 5
 #define RN_RING_SIZE (RN_RING_SLOTS * RN_FRAME_SIZE)
+// ring position of pitch_buf[0] when the newest frame sits in `slot` (its last sample = pitch_buf[1727])
+#define RN_RING0(slot) (((slot) * RN_FRAME_SIZE + RN_RING_SIZE - (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE)) % RN_RING_SIZE)
 
 struct RnTablesDev {
   const float *half_window;   // [480]   src/rnnoise_tables.c:570 (by formula)
