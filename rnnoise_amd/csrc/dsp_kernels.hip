@@ -31,12 +31,14 @@ __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.r + b.r, a.i + b.i
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i}; }
 
 // digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346 on factors {5,192,3,64,4,16,4,4,4,1})
-__device__ __forceinline__ int bitrev960(int i) {
+__device__ __forceinline__ int bitrev960_calc(int i) {
   int j0 = i % 5, q = i / 5;
   int j1 = q % 3; q /= 3;
   int j2 = q & 3, j3 = (q >> 2) & 3, j4 = q >> 4;
   return j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4;
 }
+// the same permutation from a 960-entry u16 table built on the host (one cached load instead of ~15 VALU)
+#define bitrev960(i) ((int)tb.bitrev[(i)])
 
 // In-place 960-point forward FFT on LDS data already scaled by 1/960 and digit-reversed
 // (src/kiss_fft.c:518-564 stage order 4,4,4,3,5; butterflies :101-306).  Butterflies of a
@@ -175,10 +177,12 @@ __device__ __forceinline__ float interp_gain_bin(const float *bandE, int bin, co
   return (1 - frac) * bandE[i - 1] + frac * bandE[i];
 }
 
-// src/denoise.c:160-170, lane i < 32 produces out[i]
-__device__ __forceinline__ float dct_lane(const float *in, int i, const RnTablesDev &tb) {
+// src/denoise.c:160-170, lane i < 32 produces out[i]; c[j] = rnn_dct_table[j*32 + i], fetched by the
+// caller well before use (the 32 loads are independent of the sum chain)
+__device__ __forceinline__ float dct_lane(const float *in, const float *c, const RnTablesDev &tb) {
   float sum = 0;
-  for (int j = 0; j < RN_NB_BANDS; j++) sum += in[j] * tb.dct[j * RN_NB_BANDS + i];
+#pragma unroll
+  for (int j = 0; j < RN_NB_BANDS; j++) sum += in[j] * c[j];
   return (float)(sum * tb.dct_scale);
 }
 
@@ -224,8 +228,7 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
   }
   __syncthreads();
   float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-  bp0 = 0;
-  bp1 = 1;
+  int p0 = 0, p1 = 1;  // locals (not the reference parameters): keeps the selection in registers
   for (int base = 0; base < max_pitch; base += WAVE) {
     const int i = base + lane;
     const float xc = (i < max_pitch) ? xcorr[i] : 0.f;
@@ -237,16 +240,20 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
       const float x16 = xcorr[idx] * 1e-12f;
       const float num = x16 * x16;
       const float S = syy[idx];
-      if (num * bd1 > bn1 * S) {
-        if (num * bd0 > bn0 * S) {
-          bn1 = bn0; bd1 = bd0; bp1 = bp0;
-          bn0 = num; bd0 = S; bp0 = idx;
-        } else {
-          bn1 = num; bd1 = S; bp1 = idx;
-        }
-      }
+      const bool c1 = num * bd1 > bn1 * S;
+      const bool c0 = num * bd0 > bn0 * S;
+      // reference order: test [1] first, then [0]; a hit on [0] shifts the old best down (pitch.c:69-87)
+      const bool top = c1 && c0, second = c1 && !c0;
+      bn1 = top ? bn0 : (second ? num : bn1);
+      bd1 = top ? bd0 : (second ? S : bd1);
+      p1 = top ? p0 : (second ? idx : p1);
+      bn0 = top ? num : bn0;
+      bd0 = top ? S : bd0;
+      p0 = top ? idx : p0;
     }
   }
+  bp0 = p0;
+  bp1 = p1;
   __syncthreads();
 }
 
@@ -371,7 +378,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
-#define PB(i) ring[(ring0 + (i)) % RN_RING_SIZE]  // pitch_buf[i], i in [0, 1728)
+  auto pb_at = [&](int i) {  // pitch_buf[i], i in [0, 1728): ring0 + i < 2 * RN_RING_SIZE, one conditional wrap
+    int p = ring0 + i;
+    p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
+    return ring[p];
+  };
+#define PB(i) pb_at(i)
 
   CLK_TAP(0);
   CLK_TAP(1);
@@ -660,6 +672,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 
   CLK_TAP(10);  // doubling decisions + 3 final dots
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
+  float dctc[RN_NB_BANDS];  // this lane's DCT column, requested now, consumed after the FFT
+#pragma unroll
+  for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
   for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
     float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i) * w;
@@ -688,7 +703,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *feat = g.features + (size_t)s * 68;
   float f_hi = 0;
   if (lane < RN_NB_BANDS) {
-    f_hi = dct_lane(Exp, lane, tb);
+    f_hi = dct_lane(Exp, dctc, tb);
     Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
   }
   __syncthreads();
@@ -712,7 +727,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const int silence = TRAIN ? (((double)E < 0.1) ? 1 : 0) : (((double)E < 0.04) ? 1 : 0);
   const bool zero = !TRAIN && silence;
   if (lane < RN_NB_BANDS) {
-    float f_lo = dct_lane(Ly, lane, tb);
+    float f_lo = dct_lane(Ly, dctc, tb);
     if (lane == 0) f_lo -= 12;
     if (lane == 1) f_lo -= 4;
     feat[lane] = zero ? 0.f : f_lo;

@@ -286,6 +286,11 @@ int tables_for_device(int device, RnTablesDev &out) {
     }
   std::vector<float> window(RN_FRAME_SIZE), dct(RN_NB_BANDS * RN_NB_BANDS), tw(2 * RN_WINDOW_SIZE), frac(400);
   std::vector<uint8_t> band_of(400);
+  std::vector<uint16_t> bitrev(RN_WINDOW_SIZE);
+  for (int i = 0; i < RN_WINDOW_SIZE; i++) {  // digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346)
+    int j0 = i % 5, j1 = (i / 5) % 3, j2 = (i / 15) % 4, j3 = (i / 60) % 4, j4 = i / 240;
+    bitrev[i] = (uint16_t)(j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4);
+  }
   for (int i = 0; i < RN_FRAME_SIZE; i++) {
     double a = .5 * M_PI * (i + .5) / RN_FRAME_SIZE;
     window[i] = (float)sin(.5 * M_PI * sin(a) * sin(a));
@@ -312,7 +317,8 @@ int tables_for_device(int device, RnTablesDev &out) {
   Staging st;
   size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
          o_t = st.add(tw.data(), 4 * tw.size()), o_f = st.add(frac.data(), 4 * frac.size()),
-         o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(RN_RCP_LUT_X86, sizeof RN_RCP_LUT_X86);
+         o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(RN_RCP_LUT_X86, sizeof RN_RCP_LUT_X86),
+         o_br = st.add(bitrev.data(), 2 * bitrev.size());
   DeviceTables t;
   t.device = device;
   HIP_OK(hipSetDevice(device));
@@ -324,6 +330,7 @@ int tables_for_device(int device, RnTablesDev &out) {
   t.dev.twiddles = reinterpret_cast<const float *>(base + o_t);
   t.dev.band_frac = reinterpret_cast<const float *>(base + o_f);
   t.dev.band_of_bin = base + o_b;
+  t.dev.bitrev = reinterpret_cast<const uint16_t *>(base + o_br);
   t.dev.rcp_lut = reinterpret_cast<const uint32_t *>(base + o_r);
   t.dev.dct_scale = sqrt(2. / 22);
   g_tables.push_back(t);
