@@ -833,12 +833,11 @@ __device__ void band_chain_finish(float *bandE, const float *Q, float *sums, int
 // pays one memory round trip instead of one per stage.  8.4 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity) {
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity, int prev) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x;
   const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
-  const int prev = parity ^ 1;
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
@@ -976,8 +975,8 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
                      parity, *tr);
   return hipGetLastError();
 }
-extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int parity,
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int cur, int prev,
                                           hipStream_t st) {
-  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, out, parity);
+  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, out, cur, prev);
   return hipGetLastError();
 }

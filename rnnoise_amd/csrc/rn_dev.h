@@ -16,6 +16,9 @@
 #include "../../include/rn_layout.h"
 
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
+// spectra slots: frame t writes slot t%3, synthesis of frame t reads slots t%3 (Ex) and (t-1)%3 (the
+// reference's delayed_*); the third slot lets the analysis of frame t+1 run beside synthesis of frame t
+#define RN_SPEC_SLOTS 3
 // pitch ring: the 1728-sample pitch_buf (3.6 frames) lives in a ring of 480-sample slots and is never
 // shifted.  Five slots rather than four, so that the high-pass kernel may already write frame t+1
 // while the analysis kernel still reads frame t's 1728 samples (they touch disjoint slots).
@@ -66,13 +69,16 @@ struct RnGroupDev {
   float *conv1_state;  // [N][130]
   float *conv2_state;  // [N][256]
   float *gru_state;    // [3][N][384]
-  float *spec_X[2];    // [N][RN_SPEC_STRIDE]  current / delayed by parity
-  float *spec_P[2];    // [N][RN_SPEC_STRIDE]
-  float *spec_E[2];    // [N][96] = Ex | Ep | Exp
+  float *spec_X[RN_SPEC_SLOTS];  // [N][RN_SPEC_STRIDE]  rotating: current, delayed, (free for the next frame)
+  float *spec_P[RN_SPEC_SLOTS];  // [N][RN_SPEC_STRIDE]
+  float *spec_E[RN_SPEC_SLOTS];  // [N][96] = Ex | Ep | Exp
   // per-step scratch
   float *features;     // [N][68] (65 used)
   int *silence;        // [N]
   int *pitch;          // [N]   final period (debug/tests)
+  float *features_b;   // second copy of the three per-step arrays above (the host alternates them per frame
+  int *silence_b;      //   so that the analysis of frame t+1 may overlap network/synthesis of frame t)
+  int *pitch_b;
   float *gains;        // [N][32] raw network gains of the current step
   float *vad;          // [N]
   float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)

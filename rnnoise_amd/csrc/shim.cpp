@@ -20,7 +20,7 @@
 
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t);
-extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t);
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *, const RnTablesDev *, const float *, int, int,
                                                const RnTrainArgs *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
@@ -364,12 +364,16 @@ struct RNNModel {
 
 struct RNNoiseBatch {
   RNNModel *model = nullptr;
-  int device = 0, n = 0, parity = 0, nn_path = 0;
+  int device = 0, n = 0, nn_path = 0;
+  int parity = 0;  // spectra slot (mod RN_SPEC_SLOTS) the next frame writes; the previous one holds the delayed spectra
+  long frame_no = 0;  // selects the per-step scratch copy (features / silence / pitch are double-buffered)
+  float *features2[2] = {nullptr, nullptr};
+  int *silence2[2] = {nullptr, nullptr}, *pitch2[2] = {nullptr, nullptr};
   int ring_slot = 0;  // pitch-ring slot the next frame is written to
   // side stream + events: in multi-frame calls the (latency-bound, 1 lane per stream) high-pass of frame
   // f+1 runs beside analysis/network/synthesis of frame f
   hipStream_t side = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_hp[2] = {nullptr, nullptr}, ev_k1[2] = {nullptr, nullptr};
+  hipEvent_t ev_begin = nullptr, ev_k1[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k3[4] = {nullptr, nullptr, nullptr, nullptr};
   void *arena = nullptr;
   size_t arena_bytes = 0;
   RnGroupDev g{};
@@ -458,7 +462,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.conv1_state = carve<float>(p, 130 * N);
   g.conv2_state = carve<float>(p, 256 * N);
   g.gru_state = carve<float>(p, 3 * RN_GRU * N);
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < RN_SPEC_SLOTS; k++) {
     g.spec_X[k] = carve<float>(p, RN_SPEC_STRIDE * N);
     g.spec_P[k] = carve<float>(p, RN_SPEC_STRIDE * N);
     g.spec_E[k] = carve<float>(p, 96 * N);
@@ -466,6 +470,9 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.features = carve<float>(p, 68 * N);
   g.silence = carve<int>(p, N);
   g.pitch = carve<int>(p, N);
+  g.features_b = carve<float>(p, 68 * N);
+  g.silence_b = carve<int>(p, N);
+  g.pitch_b = carve<int>(p, N);
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
   g.nn_act = carve<float>(p, RN_GRU * N);
@@ -548,6 +555,12 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   batch_layout(b->g, static_cast<uint8_t *>(b->arena), n_streams);
   b->scratch_gains = b->g.gains;
   b->scratch_vad = b->g.vad;
+  b->features2[0] = b->g.features;
+  b->silence2[0] = b->g.silence;
+  b->pitch2[0] = b->g.pitch;
+  b->features2[1] = b->g.features_b;
+  b->silence2[1] = b->g.silence_b;
+  b->pitch2[1] = b->g.pitch_b;
   if (rnnoise_batch_reset(b)) {
     rnnoise_batch_destroy(b);
     return nullptr;
@@ -570,7 +583,7 @@ extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (b->side) {
     hipStreamDestroy(b->side);
     hipEventDestroy(b->ev_begin);
-    for (int k = 0; k < 2; k++) { hipEventDestroy(b->ev_hp[k]); hipEventDestroy(b->ev_k1[k]); }
+    for (int k = 0; k < 4; k++) { hipEventDestroy(b->ev_k1[k]); hipEventDestroy(b->ev_k3[k]); }
   }
   delete b;
 }
@@ -583,6 +596,7 @@ extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
   b->parity = 0;
   b->ring_slot = 0;
+  b->frame_no = 0;
   return 0;
 }
 
@@ -600,39 +614,59 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   HIP_OK(hipSetDevice(b->device));
   const size_t N = b->n;
-  // worthwhile while the high-pass kernel is latency-bound (few waves); at large batches it would
-  // only compete with the network kernel for issue slots (measured: +2 % at 4096, -2 % at 65536 streams)
-  const bool overlap = n_frames > 1 && b->n <= 16384;
-  if (overlap && !b->side) {
+  // Multi-frame calls are software-pipelined over two streams: B runs high-pass + analysis of frame f+1
+  // while A (the caller's stream) runs network + synthesis of frame f.  What makes that legal:
+  //   * the spectra rotate through 3 slots and the per-step scratch (features, silence, pitch) is
+  //     double-buffered, so analysis(f) only has to wait for synthesis(f-2);
+  //   * the pitch ring has 5 slots, so high-pass(f+1) never writes what analysis(f) reads;
+  //   * every other piece of state is touched by one kernel only.
+  const bool pipelined = n_frames > 1;
+  if (pipelined && !b->side) {
     HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) {
-      HIP_OK(hipEventCreateWithFlags(&b->ev_hp[k], hipEventDisableTiming));
+    for (int k = 0; k < 4; k++) {
       HIP_OK(hipEventCreateWithFlags(&b->ev_k1[k], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], hipEventDisableTiming));
     }
   }
-  if (overlap) {  // the side stream starts after everything already queued on the caller's stream
+  hipStream_t sb = pipelined ? b->side : st;
+  if (pipelined) {  // B starts after everything already queued on the caller's stream
     HIP_OK(hipEventRecord(b->ev_begin, st));
     HIP_OK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
-    HIP_OK(rn_launch_hp(&b->g, d_in, b->ring_slot, b->side));
-    HIP_OK(hipEventRecord(b->ev_hp[0], b->side));
   }
-  for (int f = 0; f < n_frames; f++) {
+  auto frame_group = [&](int f) {
     RnGroupDev g = b->g;
+    const int c = (int)((b->frame_no + f) & 1);
+    g.features = b->features2[c];
+    g.silence = b->silence2[c];
+    g.pitch = b->pitch2[c];
     g.vad = d_vad ? d_vad + f * N : b->scratch_vad;
     g.gains = d_gains ? d_gains + f * N * RN_NB_BANDS : b->scratch_gains;
-    {
-      ScopedEvent ev(b, st, 0);
-      if (overlap) HIP_OK(hipStreamWaitEvent(st, b->ev_hp[f & 1], 0));
-      else HIP_OK(rn_launch_hp(&g, d_in + f * N * RN_FRAME_SIZE, b->ring_slot, st));
-      HIP_OK(rn_launch_analysis(&g, &b->tb, b->ring_slot, b->parity, st));
-    }
-    if (overlap && f + 1 < n_frames) {
-      // K0(f+1) writes slot+1, which K1(f) does not read (5 slots), but K1(f-1) did: wait for it.
-      if (f >= 1) HIP_OK(hipStreamWaitEvent(b->side, b->ev_k1[(f - 1) & 1], 0));
-      HIP_OK(rn_launch_hp(&b->g, d_in + (f + 1) * N * RN_FRAME_SIZE, (b->ring_slot + 1) % RN_RING_SLOTS, b->side));
-      HIP_OK(hipEventRecord(b->ev_hp[(f + 1) & 1], b->side));
-      HIP_OK(hipEventRecord(b->ev_k1[f & 1], st));
+    return g;
+  };
+  auto front = [&](int f) -> int {  // high-pass + analysis of frame f on stream sb
+    RnGroupDev g = frame_group(f);
+    if (pipelined && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 3], 0));
+    ScopedEvent ev(b, sb, 0);
+    HIP_OK(rn_launch_hp(&g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sb));
+    HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb));
+    return 0;
+  };
+  if (pipelined) {
+    if (front(0)) return -1;
+    HIP_OK(hipEventRecord(b->ev_k1[0], sb));
+  }
+  for (int f = 0; f < n_frames; f++) {
+    RnGroupDev g = frame_group(f);
+    const int cur = (b->parity + f) % RN_SPEC_SLOTS, prev = (cur + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
+    if (!pipelined) {
+      if (front(f)) return -1;
+    } else {
+      if (f + 1 < n_frames) {  // queue the next frame's front half before this frame's back half
+        if (front(f + 1)) return -1;
+        HIP_OK(hipEventRecord(b->ev_k1[(f + 1) & 3], sb));
+      }
+      HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 3], 0));
     }
     {
       ScopedEvent ev(b, st, 1);
@@ -641,12 +675,14 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     }
     {
       ScopedEvent ev(b, st, 2);
-      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, b->parity, st));
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st));
     }
-    b->parity ^= 1;
-    b->ring_slot = (b->ring_slot + 1) % RN_RING_SLOTS;
+    if (pipelined) HIP_OK(hipEventRecord(b->ev_k3[f & 3], st));
     b->launches += b->timing ? 1 : 0;
   }
+  b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;
+  b->ring_slot = (b->ring_slot + n_frames) % RN_RING_SLOTS;
+  b->frame_no += n_frames;
   return 0;
 }
 
@@ -696,7 +732,7 @@ extern "C" int rnnoise_batch_train_features_device(RNNoiseBatch *b, float *d_rec
     tr.noise_free = d_noise_free;
     tr.rec = d_records + f * N * 98;
     HIP_OK(rn_launch_train_features(&b->g, &b->tb, d_noisy + f * N * RN_FRAME_SIZE, b->ring_slot, b->parity, &tr, st));
-    b->parity ^= 1;
+    b->parity = (b->parity + 1) % RN_SPEC_SLOTS;
     b->ring_slot = (b->ring_slot + 1) % RN_RING_SLOTS;
   }
   return 0;
@@ -739,7 +775,7 @@ extern "C" int rnnoise_batch_export_state(RNNoiseBatch *b, int s, float *f) {
   HIP_OK(hipDeviceSynchronize());
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
-  const int last = b->parity ^ 1;  // slot written by the most recent frame = the "delayed" spectra
+  const int last = (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;  // slot of the most recent frame = the "delayed" spectra
   {  // un-rotate the pitch ring: pitch_buf[i] = ring[(ring0 + i) % RN_RING_SIZE]
     float ring[RN_RING_SIZE];
     D2H(ring, g.pitch_ring + S * RN_RING_SIZE, RN_RING_SIZE);
@@ -771,7 +807,7 @@ extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f
   HIP_OK(hipDeviceSynchronize());
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
-  const int last = b->parity ^ 1;
+  const int last = (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
   {
     float ring[RN_RING_SIZE] = {0};
     const int ring0 = RN_RING0((b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS);
@@ -809,11 +845,11 @@ extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *s
   HIP_OK(hipDeviceSynchronize());
   if (features) {
     std::vector<float> tmp((size_t)b->n * 68);
-    D2H(tmp.data(), b->g.features, tmp.size());
+    D2H(tmp.data(), b->features2[(b->frame_no + 1) & 1], tmp.size());
     for (int s = 0; s < b->n; s++) memcpy(features + (size_t)s * RN_NB_FEATURES, tmp.data() + (size_t)s * 68, RN_NB_FEATURES * 4);
   }
-  if (silence) D2H(silence, b->g.silence, b->n);
-  if (pitch) D2H(pitch, b->g.pitch, b->n);
+  if (silence) D2H(silence, b->silence2[(b->frame_no + 1) & 1], b->n);
+  if (pitch) D2H(pitch, b->pitch2[(b->frame_no + 1) & 1], b->n);
   return 0;
 }
 
