@@ -20,9 +20,9 @@
 // reference's delayed_*); the third slot lets the analysis of frame t+1 run beside synthesis of frame t
 #define RN_SPEC_SLOTS 3
 // pitch ring: the 1728-sample pitch_buf (3.6 frames) lives in a ring of 480-sample slots and is never
-// shifted.  Five slots rather than four, so that the high-pass kernel may already write frame t+1
-// while the analysis kernel still reads frame t's 1728 samples (they touch disjoint slots).
-#define RN_RING_SLOTS 5
+// shifted.  Six slots rather than four: the analysis of frame t reads slots t-3..t, so the high-pass
+// kernel may run up to two frames ahead (it writes slot t+1 or t+2) without touching what is being read.
+#define RN_RING_SLOTS 6
 #define RN_RING_SIZE (RN_RING_SLOTS * RN_FRAME_SIZE)
 // ring position of pitch_buf[0] when the newest frame sits in `slot` (its last sample = pitch_buf[1727])
 #define RN_RING0(slot) (((slot) * RN_FRAME_SIZE + RN_RING_SIZE - (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE)) % RN_RING_SIZE)

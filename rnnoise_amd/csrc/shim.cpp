@@ -372,8 +372,8 @@ struct RNNoiseBatch {
   int ring_slot = 0;  // pitch-ring slot the next frame is written to
   // side stream + events: in multi-frame calls the (latency-bound, 1 lane per stream) high-pass of frame
   // f+1 runs beside analysis/network/synthesis of frame f
-  hipStream_t side = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_k1[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k3[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t side = nullptr, side_hp = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_hp[8] = {}, ev_k1[8] = {}, ev_k3[8] = {};
   void *arena = nullptr;
   size_t arena_bytes = 0;
   RnGroupDev g{};
@@ -582,8 +582,9 @@ extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (b->debug_buf) hipFree(b->debug_buf);
   if (b->side) {
     hipStreamDestroy(b->side);
+    hipStreamDestroy(b->side_hp);
     hipEventDestroy(b->ev_begin);
-    for (int k = 0; k < 4; k++) { hipEventDestroy(b->ev_k1[k]); hipEventDestroy(b->ev_k3[k]); }
+    for (int k = 0; k < 8; k++) { hipEventDestroy(b->ev_hp[k]); hipEventDestroy(b->ev_k1[k]); hipEventDestroy(b->ev_k3[k]); }
   }
   delete b;
 }
@@ -614,25 +615,30 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   HIP_OK(hipSetDevice(b->device));
   const size_t N = b->n;
-  // Multi-frame calls are software-pipelined over two streams: B runs high-pass + analysis of frame f+1
-  // while A (the caller's stream) runs network + synthesis of frame f.  What makes that legal:
+  // Multi-frame calls are software-pipelined over three streams: C runs the high-pass of frames up to
+  // f+2, B the analysis of frame f+1, A (the caller's stream) network + synthesis of frame f.
+  // What makes that legal:
+  //   * the pitch ring has 6 slots and analysis(g) reads slots g-3..g, so high-pass(f) only has to wait
+  //     for analysis(f-3);
   //   * the spectra rotate through 3 slots and the per-step scratch (features, silence, pitch) is
   //     double-buffered, so analysis(f) only has to wait for synthesis(f-2);
-  //   * the pitch ring has 5 slots, so high-pass(f+1) never writes what analysis(f) reads;
-  //   * every other piece of state is touched by one kernel only.
+  //   * every other piece of state is touched by one kernel only, in frame order on its own stream.
   const bool pipelined = n_frames > 1;
   if (pipelined && !b->side) {
     HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming));
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 8; k++) {
+      HIP_OK(hipEventCreateWithFlags(&b->ev_hp[k], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&b->ev_k1[k], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], hipEventDisableTiming));
     }
   }
-  hipStream_t sb = pipelined ? b->side : st;
-  if (pipelined) {  // B starts after everything already queued on the caller's stream
+  hipStream_t sb = pipelined ? b->side : st, sc = pipelined ? b->side_hp : st;
+  if (pipelined) {  // B and C start after everything already queued on the caller's stream
     HIP_OK(hipEventRecord(b->ev_begin, st));
     HIP_OK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
+    HIP_OK(hipStreamWaitEvent(b->side_hp, b->ev_begin, 0));
   }
   auto frame_group = [&](int f) {
     RnGroupDev g = b->g;
@@ -644,29 +650,39 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     g.gains = d_gains ? d_gains + f * N * RN_NB_BANDS : b->scratch_gains;
     return g;
   };
-  auto front = [&](int f) -> int {  // high-pass + analysis of frame f on stream sb
+  auto highpass = [&](int f) -> int {  // K0 of frame f on stream sc
+    if (pipelined && f >= 3) HIP_OK(hipStreamWaitEvent(sc, b->ev_k1[(f - 3) & 7], 0));
+    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc));
+    if (pipelined) HIP_OK(hipEventRecord(b->ev_hp[f & 7], sc));
+    return 0;
+  };
+  auto analysis = [&](int f) -> int {  // K1 of frame f on stream sb
     RnGroupDev g = frame_group(f);
-    if (pipelined && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 3], 0));
-    ScopedEvent ev(b, sb, 0);
-    HIP_OK(rn_launch_hp(&g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sb));
-    HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb));
+    if (pipelined) {
+      HIP_OK(hipStreamWaitEvent(sb, b->ev_hp[f & 7], 0));
+      if (f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 7], 0));
+    }
+    {
+      ScopedEvent ev(b, sb, 0);
+      HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb));
+    }
+    if (pipelined) HIP_OK(hipEventRecord(b->ev_k1[f & 7], sb));
     return 0;
   };
   if (pipelined) {
-    if (front(0)) return -1;
-    HIP_OK(hipEventRecord(b->ev_k1[0], sb));
+    for (int f = 0; f < 3 && f < n_frames; f++)
+      if (highpass(f)) return -1;
+    if (analysis(0)) return -1;
   }
   for (int f = 0; f < n_frames; f++) {
     RnGroupDev g = frame_group(f);
     const int cur = (b->parity + f) % RN_SPEC_SLOTS, prev = (cur + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
     if (!pipelined) {
-      if (front(f)) return -1;
+      if (highpass(f) || analysis(f)) return -1;
     } else {
-      if (f + 1 < n_frames) {  // queue the next frame's front half before this frame's back half
-        if (front(f + 1)) return -1;
-        HIP_OK(hipEventRecord(b->ev_k1[(f + 1) & 3], sb));
-      }
-      HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 3], 0));
+      if (f + 3 < n_frames && highpass(f + 3)) return -1;
+      if (f + 1 < n_frames && analysis(f + 1)) return -1;
+      HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 7], 0));
     }
     {
       ScopedEvent ev(b, st, 1);
@@ -677,7 +693,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       ScopedEvent ev(b, st, 2);
       HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st));
     }
-    if (pipelined) HIP_OK(hipEventRecord(b->ev_k3[f & 3], st));
+    if (pipelined) HIP_OK(hipEventRecord(b->ev_k3[f & 7], st));
     b->launches += b->timing ? 1 : 0;
   }
   b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;
