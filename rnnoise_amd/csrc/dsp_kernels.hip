@@ -346,6 +346,38 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
 //   pitch phase  : xlp [0,864) | squares [864,1728) (4x-decimated copy y4 in its upper part during
 //                  the coarse search) | running energies [1728,2024) | xcorr [2024,2320); yy_lookup
 //                  and the dot products reuse [1728,2184) once the searches are done
+// two independent dot-product chains per lane (lags `ya` and `yb` against the same x): the pair is
+// written as 2-wide vector arithmetic so that it compiles to v_pk_mul_f32 / v_pk_add_f32 -- half the
+// VALU instructions of two scalar chains; each component is still mul-then-add in the reference order.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f chain_dot8_x2(const float *x, const float *ya, const float *yb, int n) {
+  v2f s = {0.f, 0.f};
+  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
+  v2f y[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) y[k] = v2f{ya[k], yb[k]};
+  for (int i = 0; i < n; i += 8) {
+    const int nx = (i + 8 < n) ? i + 8 : i;
+    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
+    v2f yn[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) yn[k] = v2f{ya[nx + k], yb[nx + k]};
+    s = s + v2f{xa.x, xa.x} * y[0];
+    s = s + v2f{xa.y, xa.y} * y[1];
+    s = s + v2f{xa.z, xa.z} * y[2];
+    s = s + v2f{xa.w, xa.w} * y[3];
+    s = s + v2f{xb.x, xb.x} * y[4];
+    s = s + v2f{xb.y, xb.y} * y[5];
+    s = s + v2f{xb.z, xb.z} * y[6];
+    s = s + v2f{xb.w, xb.w} * y[7];
+    xa = xc;
+    xb = xd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = yn[k];
+  }
+  return s;
+}
+
 struct AnalysisLds {
   float a[2560];
 };
@@ -503,7 +535,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
   for (int j = lane; j < 432; j += WAVE) y4[j] = xlp[2 * j];
   __syncthreads();
-  for (int lag = lane; lag < 147; lag += WAVE) xc[lag] = chain_dot8(y4 + 192, y4 + lag, 240);
+  {  // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
+    const v2f p = chain_dot8_x2(y4 + 192, y4 + lane, y4 + lane + 64, 240);
+    xc[lane] = p.x;
+    xc[lane + 64] = p.y;
+    if (lane < 147 - 128) xc[lane + 128] = chain_dot8(y4 + 192, y4 + lane + 128, 240);
+  }
   __syncthreads();
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
