@@ -280,7 +280,7 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // 
 // fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
+rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp) {
   const int s = blockIdx.x * WAVE + threadIdx.x;
   if (s >= g.n_streams) return;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
@@ -301,12 +301,112 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
       m1 = (float)fma(na1, yd, xd);                                  \
       (yo) = yi;                                                     \
     }
-    HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+    if (apply_hp) {
+      HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+    } else {
+      o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
+    }
 #undef HP_STEP
     y[i] = o;
   }
-  g.mem_hp[2 * s] = m0;
-  g.mem_hp[2 * s + 1] = m1;
+  if (apply_hp) {
+    g.mem_hp[2 * s] = m0;
+    g.mem_hp[2 * s + 1] = m1;
+  }
+
+  // ---- rnn_pitch_downsample's serial half (src/pitch.c:146-214): 2x decimation, 5-lag autocorrelation
+  // (src/celt_lpc.c:92-174), lag window, order-4 Levinson (src/celt_lpc.c:38-89) -> the 5 FIR taps.
+  // In the wave-per-frame kernel these 5 chains of 864 steps used 5 lanes of 64; here every lane
+  // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
+  // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
+  // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
+  {
+    const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
+    const int ring0 = RN_RING0(slot);
+    auto chunk = [&](int c) {  // pitch_buf[4c .. 4c+3]; ring0 and the ring size are multiples of 4
+      int p = ring0 + 4 * c;
+      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
+      return *reinterpret_cast<const float4 *>(ring + p);
+    };
+    float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
+    float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
+    float prev = 0;                          // pitch_buf[4c-1]
+    float4 q = chunk(0);
+    for (int c = 0; c < RN_PITCH_BUF_SIZE / 4; c++) {
+      const float4 v = q;
+      if (c + 1 < RN_PITCH_BUF_SIZE / 4) q = chunk(c + 1);
+      float xl[2];
+      xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
+      xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
+      prev = v.w;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int t = 2 * c + h;
+        const float x0 = xl[h];
+        if (t < 860) {
+          ac[0] = ac[0] + x0 * x0;
+          ac[1] = ac[1] + w1 * x0;
+          ac[2] = ac[2] + w2 * x0;
+          ac[3] = ac[3] + w3 * x0;
+          ac[4] = ac[4] + w4 * x0;
+        } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
+          const int e = t - 860;
+          d[0] = d[0] + x0 * x0;
+          if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
+          if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
+          if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
+          ac[4] = ac[4] + w4 * x0;
+        }
+        w4 = w3; w3 = w2; w2 = w1; w1 = x0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
+    ac[0] *= 1.0001f;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+    float lpc[4] = {0, 0, 0, 0};
+    if (ac[0] != 0) {
+      float error = ac[0];
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (!done) {
+          float rr = 0;
+#pragma unroll
+          for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+          rr += ac[i + 1];
+          const float r = -rr / error;
+          lpc[i] = r;
+#pragma unroll
+          for (int j = 0; j < (i + 1) >> 1; j++) {
+            const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+            lpc[j] = t1 + r * t2;
+            lpc[i - 1 - j] = t2 + r * t1;
+          }
+          error = error - (r * r) * error;
+          if (error < .001f * ac[0]) done = true;  // `break` (celt_lpc.c:81-82)
+        }
+      }
+    }
+    float tmp = 1.f;
+    const float c1 = .8f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      tmp = .9f * tmp;
+      lpc[i] = lpc[i] * tmp;
+    }
+    float *o = g.lpc2 + ((size_t)slot * g.n_streams + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
+    o[0] = lpc[0] + .8f;
+    o[1] = lpc[1] + c1 * lpc[0];
+    o[2] = lpc[2] + c1 * lpc[1];
+    o[3] = lpc[3] + c1 * lpc[2];
+    o[4] = c1 * lpc[3];
+    if (g.debug) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
+    }
+  }
 }
 
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
@@ -397,8 +497,9 @@ struct AnalysisLds {
 // `ring0` = physical ring position of pitch_buf[0] (src/denoise.c:359-360 shift = ring rotation).
 // ---------------------------------------------------------------------------------------------
 template <bool TRAIN>
-__device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int ring0, int parity,
+__device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot, int parity,
                                               const RnTrainArgs &tr) {
+  const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x;
@@ -447,62 +548,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     xlp[i] = v;
   }
   __syncthreads();
+  // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
   float lpc2[5];
-  {
-    // rnn_autocorr lags 0..4 (src/celt_lpc.c:92-174): lane k owns lag k
-    float ack = 0;
-    if (lane < 5) {
-      const int k = lane;
-      float sacc = chain_dot8(xlp, xlp + k, 856), d = 0;
-      for (int i = 856; i < 860; i++) sacc = sacc + xlp[i] * xlp[i + k];
-      for (int i = k + 860; i < 864; i++) d = d + xlp[i] * xlp[i - k];
-      ack = sacc + d;
-    }
-    float ac[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) ac[k] = __shfl(ack, k);
-    ac[0] *= 1.0001f;
-#pragma unroll
-    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
-    // rnn_lpc order 4 (src/celt_lpc.c:38-89), uniform across lanes
-    float lpc[4] = {0, 0, 0, 0};
-    if (ac[0] != 0) {
-      float error = ac[0];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float rr = 0;
-#pragma unroll
-        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-        rr += ac[i + 1];
-        float r = -rr / error;
-        lpc[i] = r;
-#pragma unroll
-        for (int j = 0; j < (i + 1) >> 1; j++) {
-          float t1 = lpc[j], t2 = lpc[i - 1 - j];
-          lpc[j] = t1 + r * t2;
-          lpc[i - 1 - j] = t2 + r * t1;
-        }
-        error = error - (r * r) * error;
-        if (error < .001f * ac[0]) break;
-      }
-    }
-    float tmp = 1.f;
-    const float c1 = .8f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      tmp = .9f * tmp;
-      lpc[i] = lpc[i] * tmp;
-    }
-    lpc2[0] = lpc[0] + .8f;
-    lpc2[1] = lpc[1] + c1 * lpc[0];
-    lpc2[2] = lpc[2] + c1 * lpc[1];
-    lpc2[3] = lpc[3] + c1 * lpc[2];
-    lpc2[4] = c1 * lpc[3];
-    if (dbg && lane < 5) {
-      dbg[RN_DBG_AC + lane] = ac[lane];
-      dbg[RN_DBG_LPC + lane] = lpc2[lane];
-    }
-  }
+  for (int k = 0; k < 5; k++) lpc2[k] = g.lpc2[((size_t)slot * g.n_streams + s) * 8 + k];
+  if (dbg && lane < 5) dbg[RN_DBG_LPC + lane] = lpc2[lane];
   {  // celt_fir5 in place (src/pitch.c:104-143): outputs are independent given the OLD samples
     float r[14];
 #pragma unroll
@@ -812,24 +862,16 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 }
 
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity) {
-  analysis_body<false>(g, tb, ring0, parity, RnTrainArgs{});
+rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
+  analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
 }
 
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int ring0, int parity, RnTrainArgs tr) {
-  analysis_body<true>(g, tb, ring0, parity, tr);
+rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnTrainArgs tr) {
+  analysis_body<true>(g, tb, slot, parity, tr);
 }
 
-// the noisy training frame enters the pitch ring unfiltered (dump_features filters while mixing)
-extern "C" __global__ void __launch_bounds__(128)
-rn_ring_store_kernel(RnGroupDev g, const float *__restrict__ in, int slot) {
-  const int s = blockIdx.x, t = threadIdx.x;
-  if (t < RN_FRAME_SIZE / 4)
-    reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE)[t] =
-        reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE)[t];
-}
 
 struct SynthLds {
   cpx F[RN_WINDOW_SIZE];  // inverse-FFT work area; band products before that
@@ -997,18 +1039,17 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
 // host-visible launch helpers -----------------------------------------------------------------
 // K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot);
+  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot, 1);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st) {
-  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, RN_RING0(slot),
-                     parity);
+  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
                                                int parity, const RnTrainArgs *tr, hipStream_t st) {
-  hipLaunchKernelGGL(rn_ring_store_kernel, dim3(g->n_streams), dim3(128), 0, st, *g, noisy, slot);
-  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, RN_RING0(slot),
+  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, noisy, slot, 0);
+  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot,
                      parity, *tr);
   return hipGetLastError();
 }

@@ -81,6 +81,7 @@ struct RnGroupDev {
   int *pitch_b;
   float *gains;        // [N][32] raw network gains of the current step
   float *vad;          // [N]
+  float *lpc2;         // [RN_RING_SLOTS][N][8] (5 used) FIR taps of rnn_pitch_downsample, produced by K0, consumed by K1
   float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)
   float *train_clean_mem;  // [N][480] analysis memory of the clean stream (training-feature extraction only)
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)

@@ -476,6 +476,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
   g.nn_act = carve<float>(p, RN_GRU * N);
+  g.lpc2 = carve<float>(p, 8 * N * RN_RING_SLOTS);
   g.train_clean_mem = carve<float>(p, RN_FRAME_SIZE * N);
   return (size_t)(p - base);
 }
