@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librnnoise_amd.so")
+LIB_PATH = os.environ.get("RNNOISE_AMD_LIB", os.path.join(HERE, "librnnoise_amd.so"))  # env override: A/B builds
 
 FRAME = 480
 NB_BANDS = 32
