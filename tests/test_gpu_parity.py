@@ -340,3 +340,43 @@ def test_mfma_sparser_model(blob_little):
         assert np.array_equal(crc_rows(got["out"][:, i]), g[f"s{s}_out_crc"])
     b.close()
     m.close()
+
+
+# ---- software pipeline bookkeeping (3 streams, 6-slot pitch ring, 3 spectra slots) ------------------
+def test_pipeline_chunking_is_invisible(model, blob_default):
+    """the same 45 frames fed as calls of 1, 2, 5, 1, 3, 7, ... frames (multi-frame calls are pipelined over
+    three HIP streams, single-frame calls are not) give the oracle's bits, whatever the call boundaries"""
+    streams = [2, 9, 33, 64, 101]
+    T = 45
+    pcm = synth.batch_pcm(streams, T, lead_silence=1)
+    pcm[17:20, 1] = 0  # a silent gap in one stream (network state must freeze across a call boundary too)
+    want = oracle_run(blob_default, pcm)
+    for path in (1, 0):
+        b = capi.Batch(model, len(streams))
+        b.set_nn_path(path)
+        outs, vads, gains = [], [], []
+        t = 0
+        for n in [1, 2, 5, 1, 3, 7, 1, 1, 4, 6, 2, 12]:
+            o, v, g = b.process(pcm[t:t + n])
+            outs.append(o); vads.append(v); gains.append(g)
+            t += n
+        assert t == T
+        assert_bits_equal(np.concatenate(outs), want["out"], f"pcm (nn path {path})")
+        assert_bits_equal(np.concatenate(gains), want["gains"], "gains")
+        assert_bits_equal(np.concatenate(vads), want["vad"], "vad")
+        for i in range(len(streams)):
+            assert_bits_equal(b.export_state(i), want["state"][i], f"state {i}")
+
+
+def test_device_call_in_place(model, blob_default):
+    """d_out == d_in (the reference demo processes in place, examples/rnnoise_demo.c:57)"""
+    torch = pytest.importorskip("torch")
+    N, T = 5, 9
+    pcm = synth.batch_pcm(range(N), T)
+    want = oracle_run(blob_default, pcm)
+    buf = torch.from_numpy(pcm).cuda()
+    b = capi.Batch(model, N)
+    b.set_nn_path(1)
+    b.process_device(buf.data_ptr(), buf.data_ptr(), 0, 0, T, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_bits_equal(buf.cpu().numpy(), want["out"], "pcm in place")
