@@ -164,8 +164,7 @@ def main():
     W = model.weight_bytes
     N, K, Wm = a.streams, a.steps, a.warmup
     batch = capi.Batch(model, N, device=local_rank)
-    if a.nn == "mfma":
-        batch.set_nn_path(1)
+    batch.set_nn_path(1 if a.nn == "mfma" else 0)
 
     # inputs resident in HBM; cycle through at most `cap` distinct frames if K+W is large
     cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))

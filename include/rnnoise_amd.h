@@ -56,7 +56,8 @@ RNNOISE_EXPORT int rnnoise_batch_export_state(RNNoiseBatch *b, int stream, float
 RNNOISE_EXPORT int rnnoise_batch_import_state(RNNoiseBatch *b, int stream, const float *state);
 
 /* Network implementation: 0 = vector path (v_dot4 / FMA chains), 1 = batched MFMA path.
- * Both produce identical bits. Returns the previous value, or -1 if unsupported. */
+ * Both produce identical bits. Default: 1 for batches of >= 16 streams (one MFMA tile), else 0.
+ * Returns the previous value, or -1 if unsupported. */
 RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);
 
 /* Weight bytes one frame touches (SURVEY 8d "W"): the numerator of the HBM-roofline

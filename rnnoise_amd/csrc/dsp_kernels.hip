@@ -192,12 +192,54 @@ __device__ __forceinline__ float chain_dot(const float *x, const float *y, int n
   return s;
 }
 
+__device__ __forceinline__ float lane_bcast(float v, int l) {  // l must be wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Best-two selection of find_best_pitch (src/pitch.c:62-92) given syy[i] = Syy before lag i.
+// The reference walks the lags in order and tests each against the CURRENT second-best; the state only
+// changes at a lag that passes that test.  So: all 64 lanes test their lag against the current state at
+// once, the first passing lag is processed exactly like the reference does (second test, shift/replace),
+// and the lanes after it are re-tested against the new state.  Lags between two passing ones saw the
+// same state in the reference, hence identical decisions; a typical frame needs < 10 rounds for 147 lags.
+__device__ __forceinline__ void best_pitch_select(const float *xcorr, const float *syy, int max_pitch, int &bp0,
+                                                  int &bp1, int lane) {
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  int p0 = 0, p1 = 1;  // locals (not the reference parameters): keeps the selection in registers
+  for (int base = 0; base < max_pitch; base += WAVE) {
+    const int i = base + lane;
+    const float xc = (i < max_pitch) ? xcorr[i] : 0.f;
+    const float S = (i < max_pitch) ? syy[i] : 1.f;
+    const float x16 = xc * 1e-12f;
+    const float num = x16 * x16;
+    unsigned long long live = __ballot(xc > 0);
+    while (live) {
+      const unsigned long long m = __ballot(num * bd1 > bn1 * S) & live;
+      if (!m) break;
+      const int bit = __ffsll((long long)m) - 1;
+      const int idx = base + bit;
+      const float n_ = lane_bcast(num, bit), S_ = lane_bcast(S, bit);
+      // reference order: [1] was just tested, now [0]; a hit on [0] shifts the old best down (pitch.c:69-87)
+      const bool top = n_ * bd0 > bn0 * S_;
+      bn1 = top ? bn0 : n_;
+      bd1 = top ? bd0 : S_;
+      p1 = top ? p0 : idx;
+      bn0 = top ? n_ : bn0;
+      bd0 = top ? S_ : bd0;
+      p0 = top ? idx : p0;
+      live &= ~((2ull << bit) - 1ull);
+    }
+  }
+  bp0 = p0;
+  bp1 = p1;
+}
+
 // src/pitch.c:44-102 (float build), restructured so that only the genuinely serial part stays
 // serial:  (1) all lanes square y[] (each product rounded once, as in the reference) and form
 // d[i] = y[i+len]^2 - y[i]^2;  (2) the running energy Syy -- a float recurrence with a clamp, hence
 // order-bound -- is swept once, 4 steps per LDS transaction, leaving Syy-before-step-i in syy[i];
-// (3) the best-two selection replays the reference's sequential comparisons, but only over the lags
-// with xcorr > 0 (a ballot), which is all the reference's loop body looks at.
+// (3) best_pitch_select.  Used for the coarse (4x decimated) search; the fine search shares its sweep
+// with yy_lookup (energy_sweeps below).
 // sq: scratch >= len + max_pitch (+3) floats; syy: scratch >= max_pitch rounded up to 4.
 __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, float *sq, float *syy,
                                 int &bp0, int &bp1, int lane) {
@@ -209,7 +251,7 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
   __syncthreads();
   for (int i = lane; i < mp4; i += WAVE) syy[i] = sq[i + len] - sq[i];
   float Syy = 1;
-  for (int j = 0; j < len; j += 4) {  // len is 240 or 480
+  for (int j = 0; j < len; j += 4) {  // len is 240
     const float4 v = *reinterpret_cast<const float4 *>(sq + j);
     Syy = Syy + v.x;
     Syy = Syy + v.y;
@@ -227,34 +269,73 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
     if (lane == 0) *reinterpret_cast<float4 *>(syy + i) = o;
   }
   __syncthreads();
-  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-  int p0 = 0, p1 = 1;  // locals (not the reference parameters): keeps the selection in registers
-  for (int base = 0; base < max_pitch; base += WAVE) {
-    const int i = base + lane;
-    const float xc = (i < max_pitch) ? xcorr[i] : 0.f;
-    unsigned long long mask = __ballot(xc > 0);
-    while (mask) {
-      const int bit = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int idx = base + bit;
-      const float x16 = xcorr[idx] * 1e-12f;
-      const float num = x16 * x16;
-      const float S = syy[idx];
-      const bool c1 = num * bd1 > bn1 * S;
-      const bool c0 = num * bd0 > bn0 * S;
-      // reference order: test [1] first, then [0]; a hit on [0] shifts the old best down (pitch.c:69-87)
-      const bool top = c1 && c0, second = c1 && !c0;
-      bn1 = top ? bn0 : (second ? num : bn1);
-      bd1 = top ? bd0 : (second ? S : bd1);
-      p1 = top ? p0 : (second ? idx : p1);
-      bn0 = top ? num : bn0;
-      bd0 = top ? S : bd0;
-      p0 = top ? idx : p0;
+  best_pitch_select(xcorr, syy, max_pitch, bp0, bp1, lane);
+  __syncthreads();
+}
+
+// The two long running-energy recurrences of the pitch stage, swept TOGETHER (lane 0 / lane 1 of the
+// same instructions; a one-lane VALU instruction costs as much issue time as a 64-lane one):
+//   lane 0: Syy of the fine find_best_pitch (src/pitch.c:56-61,93-94; y = x_lp, len 480, 294 lags)
+//           init 1 + sum_{j<480} y[j]^2, then Syy = max(1, Syy + (y[i+480]^2 - y[i]^2))
+//   lane 1: yy_lookup of remove_doubling (src/pitch.c:441-456; x = x_lp+384, N 480, 384 periods)
+//           init xx = sum_{j<480} x[j]^2, then yy = (yy + x[-i]^2) - x[N-i]^2 (clamped copy stored)
+// One step is  s = max(lo, (s + A) - B)  with (A, B, lo) = (d[i], 0, 1) for lane 0 and
+// (x[-i]^2, x[N-i]^2, -inf) for lane 1; x - 0 and max(-inf, x) change no bit.
+// rsq[k] = x_lp[863-k]^2 (864 floats): reversed, so that both init sums walk DOWN it and both of lane 1's
+// sweep operands walk UP it: A_i = rsq[479+i], B_i = rsq[i-1].  Results overwrite the A operand just
+// consumed: afterwards  Syy-before-lag-i = D[i-1] (D[-1] = init)  and  yy_lookup[i] = rsq[479+i]
+// (rsq[479] = xx), clamped at 0 by a parallel pass.  D: 16-byte aligned, D[-1..295]; zero4: 4 floats.
+// Returns xx.
+__device__ __forceinline__ float energy_sweeps(const float *xlp, float *rsq, float *D, float *zero4, int lane) {
+  for (int k = lane; k < 864; k += WAVE) {
+    const float v = xlp[863 - k];
+    rsq[k] = v * v;
+  }
+  for (int i = lane; i < 296; i += WAVE) {
+    const float a = xlp[i + 480], b = xlp[i];
+    D[i] = a * a - b * b;
+  }
+  if (lane < 4) zero4[lane] = 0.f;
+  __syncthreads();
+  float s = (lane == 0) ? 1.f : 0.f;
+  {
+    const float *p = rsq + ((lane == 0) ? 860 : 476);
+    for (int j = 0; j < 480; j += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(p - j);
+      s = s + v.w;
+      s = s + v.z;
+      s = s + v.y;
+      s = s + v.x;
     }
   }
-  bp0 = p0;
-  bp1 = p1;
+  const float xx = lane_bcast(s, 1);
+  __syncthreads();  // every lane has finished reading rsq[479] / the init operands
+  if (lane == 0) D[-1] = s;
+  if (lane == 1) rsq[479] = s;
+  {
+    float *pa = (lane == 0) ? D : rsq + 480;
+    const float *pb = (lane == 0) ? zero4 : rsq;
+    const int sb = (lane == 0) ? 0 : 4;
+    const float lo = (lane == 0) ? 1.f : -__builtin_inff();
+    float4 a = *reinterpret_cast<const float4 *>(pa), b = *reinterpret_cast<const float4 *>(pb);
+    for (int j = 0; j < 384; j += 4) {
+      pb += sb;
+      const float4 an = *reinterpret_cast<const float4 *>(pa + j + 4);  // last one reads past the operands; unused
+      const float4 bn = *reinterpret_cast<const float4 *>(pb);
+      float4 o;
+      s = fmaxf(lo, (s + a.x) - b.x); o.x = s;
+      s = fmaxf(lo, (s + a.y) - b.y); o.y = s;
+      s = fmaxf(lo, (s + a.z) - b.z); o.z = s;
+      s = fmaxf(lo, (s + a.w) - b.w); o.w = s;
+      if (lane == 1 || (lane == 0 && j < 296)) *reinterpret_cast<float4 *>(pa + j) = o;
+      a = an;
+      b = bn;
+    }
+  }
   __syncthreads();
+  for (int i = 1 + lane; i <= 384; i += WAVE) rsq[479 + i] = fmaxf(0.f, rsq[479 + i]);  // MAX32(0, yy)
+  __syncthreads();
+  return xx;
 }
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
@@ -412,6 +493,7 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
 // x 16-byte aligned (identical for all lanes), y arbitrary.  The next 8 operand pairs are fetched
 // from LDS while the current 8 are being added, so the LDS round trip is off the chain.
+#define OPAQUE(v) asm("" : "+v"(v))
 __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int n) {
   float s = 0;
   float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
@@ -424,14 +506,19 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
     float yn[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) yn[k] = y[nx + k];
-    s = s + xa.x * ya[0];
-    s = s + xa.y * ya[1];
-    s = s + xa.z * ya[2];
-    s = s + xa.w * ya[3];
-    s = s + xb.x * ya[4];
-    s = s + xb.y * ya[5];
-    s = s + xb.z * ya[6];
-    s = s + xb.w * ya[7];
+    // each product passes through an empty asm: the SLP vectoriser would otherwise pair the multiplies
+    // into v_pk_mul_f32 and pay ~1.3 register shuffles per step to feed them
+    float p0 = xa.x * ya[0], p1 = xa.y * ya[1], p2 = xa.z * ya[2], p3 = xa.w * ya[3];
+    float p4 = xb.x * ya[4], p5 = xb.y * ya[5], p6 = xb.z * ya[6], p7 = xb.w * ya[7];
+    OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
+    s = s + p0;
+    s = s + p1;
+    s = s + p2;
+    s = s + p3;
+    s = s + p4;
+    s = s + p5;
+    s = s + p6;
+    s = s + p7;
     xa = xc;
     xb = xd;
 #pragma unroll
@@ -440,28 +527,33 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
   return s;
 }
 
-// One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared:
-//   FFT phases   : F = floats [0,1920) (960 complex); the band products Q live in [1000,1864), above
-//                  the 481 bins that matter; small per-frame vectors in [2392,2560)
-//   pitch phase  : xlp [0,864) | squares [864,1728) (4x-decimated copy y4 in its upper part during
-//                  the coarse search) | running energies [1728,2024) | xcorr [2024,2320); yy_lookup
-//                  and the dot products reuse [1728,2184) once the searches are done
-// two independent dot-product chains per lane (lags `ya` and `yb` against the same x): the pair is
+// One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared
+// (float offsets, the SCR_* constants below):
+//   FFT phases   : F = [0,1920) (960 complex); the band products Q live in [1000,1864), above the 481
+//                  bins that matter; small per-frame vectors in [2392,2560)
+//   coarse search: xlp [0,864) | squares [864,1252) | y4 [1296,1728) | interleaved pairs Z [1728,2334)
+//                  during the 147 chains, then running energies [1728,1876) and xcorr [2028,2175)
+//   fine search  : xlp | reversed squares -> yy_lookup [864,1728) | energy increments -> Syy [1731,2028)
+//                  | xcorr [2028,2324) | 4 zeros [2324,2328); the 64 doubling dots reuse [2120,2184)
+// two independent dot-product chains per lane (lags l and l+64 against the same x): the pair is
 // written as 2-wide vector arithmetic so that it compiles to v_pk_mul_f32 / v_pk_add_f32 -- half the
 // VALU instructions of two scalar chains; each component is still mul-then-add in the reference order.
+// z[k] = {y[k], y[k+64]} comes from an interleaved copy, so a pair is one 8-byte LDS read that lands
+// in an aligned register pair (built from two arrays the pairs cost ~2.5 moves per step).
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f chain_dot8_x2(const float *x, const float *ya, const float *yb, int n) {
+__device__ __forceinline__ v2f chain_dot8_x2(const float *x, const v2f *z, int n) {
   v2f s = {0.f, 0.f};
   float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
   v2f y[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) y[k] = v2f{ya[k], yb[k]};
+  for (int k = 0; k < 8; k++) y[k] = z[k];
+#pragma unroll 2
   for (int i = 0; i < n; i += 8) {
     const int nx = (i + 8 < n) ? i + 8 : i;
     const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
     v2f yn[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) yn[k] = v2f{ya[nx + k], yb[nx + k]};
+    for (int k = 0; k < 8; k++) yn[k] = z[nx + k];
     s = s + v2f{xa.x, xa.x} * y[0];
     s = s + v2f{xa.y, xa.y} * y[1];
     s = s + v2f{xa.z, xa.z} * y[2];
@@ -482,11 +574,13 @@ struct AnalysisLds {
   float a[2560];
 };
 #define SCR_XLP 0
-#define SCR_SQ 864    // [864]  squares of y4 / xlp
-#define SCR_Y4 1296   // [432]  4x-decimated signal (coarse search only; squares need [864,1252) then)
-#define SCR_SYY 1728  // [296]  running energies of find_best_pitch
-#define SCR_XC 2024   // [296]  xcorr[] of pitch_search
-#define SCR_YYL 1731  // [385]  yy_lookup; index i lives at SCR_YYL+i so that i = 4m+1 is 16-byte aligned
+#define SCR_SQ 864    // [388]  squares of y4 (coarse search); [864] reversed squares of xlp, later yy_lookup
+#define SCR_Y4 1296   // [432]  4x-decimated signal (coarse search only)
+#define SCR_Z 1728    // [606]  {y4[j], y4[j+64]} pairs for the packed coarse chains
+#define SCR_SYY 1728  // [148]  running energies of the coarse find_best_pitch
+#define SCR_D 1732    // [-1..295] fine search: Syy increments, then Syy itself (16-byte aligned)
+#define SCR_XC 2028   // [296]  xcorr[] of pitch_search
+#define SCR_ZERO 2324 // [4]
 #define SCR_DOTS 2120 // [64]
 #define SCR_Q 1000    // [864]  band products
 #define SCR_MISC 2392 // sums[40] | Ex[32] | Ep[32] | Exp[32] | Ly[32]
@@ -581,26 +675,37 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   CLK_TAP(3);  // downsample + autocorr + LPC + FIR
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
-  float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *scr_sq = scr + SCR_SQ, *scr_syy = scr + SCR_SYY;
+  float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC;
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
   for (int j = lane; j < 432; j += WAVE) y4[j] = xlp[2 * j];
-  __syncthreads();
-  {  // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
-    const v2f p = chain_dot8_x2(y4 + 192, y4 + lane, y4 + lane + 64, 240);
+  {
+    v2f *Z = reinterpret_cast<v2f *>(scr + SCR_Z);
+    for (int j = lane; j < 303; j += WAVE) Z[j] = v2f{xlp[2 * j], xlp[2 * j + 128]};
+    __syncthreads();
+    // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
+    const v2f p = chain_dot8_x2(y4 + 192, Z + lane, 240);
+    float q = 0;
+    if (lane < 147 - 128) q = chain_dot8(y4 + 192, y4 + lane + 128, 240);
+    __syncthreads();  // Z is dead; xcorr goes into its area
     xc[lane] = p.x;
     xc[lane + 64] = p.y;
-    if (lane < 147 - 128) xc[lane + 128] = chain_dot8(y4 + 192, y4 + lane + 128, 240);
+    if (lane < 147 - 128) xc[lane + 128] = q;
   }
   __syncthreads();
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
-  find_best_pitch(xc, y4, 240, 147, scr_sq, scr_syy, bp0, bp1, lane);
+  find_best_pitch(xc, y4, 240, 147, scr + SCR_SQ, scr + SCR_SYY, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
   if (dbg) {
     for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
   }
   __syncthreads();
+  // running energies of the fine search and of remove_doubling, one shared sweep (y4 / squares are dead)
+  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
+  const float xx = energy_sweeps(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
+  const float *yyl = rsq + 479;  // yy_lookup[i], i = 0..384
+  CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps
   for (int i = lane; i < 294; i += WAVE) xc[i] = 0;
   __syncthreads();
   if (lane < 10) {
@@ -612,8 +717,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   __syncthreads();
   CLK_TAP(6);  // fine xcorr
-  find_best_pitch(xc, xlp, 480, 294, scr_sq, scr_syy, bp0, bp1, lane);
-  CLK_TAP(7);  // fine best-pitch scan
+  best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
+  CLK_TAP(7);  // fine best-pitch selection
   int offset = 0;
   if (bp0 > 0 && bp0 < 293) {
     float a = xc[bp0 - 1], b = xc[bp0], c = xc[bp0 + 1];
@@ -632,24 +737,23 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const int maxperiod = 384, minperiod = 30, N = 480, minperiod0 = RN_PITCH_MIN_PERIOD;
     const int *sc = c_second_check;
     const float *x = xlp + maxperiod;
-    float *yyl = scr + SCR_YYL;
     float *dots = scr + SCR_DOTS;
     int T0 = pitch_index / 2;
     const int prev_period = g.last_period[s] / 2;
     const float prev_gain = g.last_gain[s];
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
-    __syncthreads();  // y4 is dead from here on; its area becomes yy_lookup / dots
+    __syncthreads();  // the fine xcorr is dead from here on; its area becomes the dots
     // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
     // independent serial sum, so computing it speculatively changes no bit):
-    //   lane 0: xx;  lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
+    //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
     //   lanes 32..61: the +-1 neighbours of every period the decision loop can end on
     //   (T0 and T1(k)), needed by the final 3-point refinement (pitch.c:511-512).
+    //   (xx, the chain at offset 0, came out of energy_sweeps)
     {
       int off = -1;
-      if (lane == 0) off = 0;
-      else if (lane == 1) off = T0;
-      else if (lane < 30) {
+      if (lane == 1) off = T0;
+      else if (lane >= 2 && lane < 30) {
         int k = 2 + ((lane - 2) >> 1);
         int T1 = (2 * T0 + k) / (2 * k), T1b;
         if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
@@ -664,57 +768,28 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       if (off >= 0) dots[lane] = chain_dot8(x, x - off, N);
     }
     __syncthreads();
-    const float xx = dots[0];
     float xy = dots[1];
-    CLK_TAP(8);  // 30 candidate dot products of remove_doubling
-    {  // yy_lookup (pitch.c:449-456): yy = (yy + x[-i]^2) - x[N-i]^2, clamped copy stored.  Squares are
-       // formed by all lanes first; the recurrence is swept 8 steps per iteration with the next
-       // operands already in flight.
-      for (int j = lane; j < 864; j += WAVE) scr_sq[j] = xlp[j] * xlp[j];
-      __syncthreads();
-      float yy = xx;
-      if (lane == 0) yyl[0] = xx;
-      // x[-i] = xlp[384-i], x[N-i] = xlp[864-i]; i = 1..384
-      float4 a0 = *reinterpret_cast<const float4 *>(scr_sq + 380), b0 = *reinterpret_cast<const float4 *>(scr_sq + 860);
-      float4 a1 = *reinterpret_cast<const float4 *>(scr_sq + 376), b1 = *reinterpret_cast<const float4 *>(scr_sq + 856);
-      for (int i = 1; i <= maxperiod; i += 8) {
-        const int nb = (i + 8 <= maxperiod) ? i + 8 : i;
-        const float4 na0 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - nb - 3);
-        const float4 nb0 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - nb - 3);
-        const float4 na1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod - nb - 7);
-        const float4 nb1 = *reinterpret_cast<const float4 *>(scr_sq + maxperiod + N - nb - 7);
-        float4 o0, o1;
-        yy = yy + a0.w - b0.w; o0.x = fmaxf(0.f, yy);
-        yy = yy + a0.z - b0.z; o0.y = fmaxf(0.f, yy);
-        yy = yy + a0.y - b0.y; o0.z = fmaxf(0.f, yy);
-        yy = yy + a0.x - b0.x; o0.w = fmaxf(0.f, yy);
-        yy = yy + a1.w - b1.w; o1.x = fmaxf(0.f, yy);
-        yy = yy + a1.z - b1.z; o1.y = fmaxf(0.f, yy);
-        yy = yy + a1.y - b1.y; o1.z = fmaxf(0.f, yy);
-        yy = yy + a1.x - b1.x; o1.w = fmaxf(0.f, yy);
-        if (lane == 0) {
-          *reinterpret_cast<float4 *>(yyl + i) = o0;
-          *reinterpret_cast<float4 *>(yyl + i + 4) = o1;
-        }
-        a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
-      }
-    }
-    __syncthreads();
+    CLK_TAP(8);  // 59 candidate dot products of remove_doubling
     float yy = yyl[T0];
-    CLK_TAP(9);  // yy_lookup running energy
     float best_xy = xy, best_yy = yy;
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
     const float g0 = pitch_gain(xy, xx, yy);
     float gg = g0;
-    for (int k = 2; k <= 15; k++) {
-      int T1 = (2 * T0 + k) / (2 * k), T1b;
-      if (T1 < minperiod) break;
+    int cand = 0;  // which candidate won: 0 = T0, c = k-1 for T1(k)
+    {
+      // The reference loop (pitch.c:462-500) runs k = 2..15, stops at the first T1 < minperiod and keeps the
+      // LAST k whose gain beats its threshold.  Nothing in an iteration depends on an earlier one, and T1 =
+      // floor(T0/k + 1/2) does not increase with k, so: lane k evaluates iteration k, and the winner is the
+      // highest lane that is both before the stop and over its threshold.
+      const int k = lane < 2 ? 2 : (lane > 15 ? 15 : lane);
+      const int T1 = (2 * T0 + k) / (2 * k);
+      int T1b;
       if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
       else T1b = (2 * sc[k] * T0 + k) / (2 * k);
       float xy1 = dots[2 + 2 * (k - 2)], xy2 = dots[3 + 2 * (k - 2)];
       xy1 = .5f * (xy1 + xy2);
-      float yy1 = .5f * (yyl[T1] + yyl[T1b]);
-      float g1 = pitch_gain(xy1, xx, yy1);
+      const float yy1 = .5f * (yyl[T1] + yyl[T1b]);
+      const float g1 = pitch_gain(xy1, xx, yy1);
       float cont;
       int dT = T1 - prev_period;
       dT = dT < 0 ? -dT : dT;
@@ -724,11 +799,15 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       float thresh = (.3f > .7f * g0 - cont) ? .3f : .7f * g0 - cont;
       if (T1 < 3 * minperiod) thresh = (.4f > .85f * g0 - cont) ? .4f : .85f * g0 - cont;
       else if (T1 < 2 * minperiod) thresh = (.5f > .9f * g0 - cont) ? .5f : .9f * g0 - cont;
-      if (g1 > thresh) {
-        best_xy = xy1;
-        best_yy = yy1;
-        T = T1;
-        gg = g1;
+      const bool hit = lane >= 2 && lane <= 15 && T1 >= minperiod && g1 > thresh;
+      const unsigned long long m = __ballot(hit);
+      if (m) {
+        const int kb = 63 - __clzll((long long)m);
+        best_xy = lane_bcast(xy1, kb);
+        best_yy = lane_bcast(yy1, kb);
+        gg = lane_bcast(g1, kb);
+        T = __builtin_amdgcn_readlane(T1, kb);
+        cand = kb - 1;
       }
     }
     best_xy = (0 > best_xy) ? 0 : best_xy;
@@ -736,9 +815,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if (best_yy <= best_xy) pg = 1.f;
     else pg = best_xy / (best_yy + 1);
     // 3-point refinement around the selected period: xcorr[k] = <x, x-(T+k-1)> (pitch.c:511-512)
-    int cand = 0;  // which candidate won: 0 = T0, c = k-1 for T1(k)
-    for (int k = 2; k <= 15; k++)
-      if (T != T0 && T == (2 * T0 + k) / (2 * k)) { cand = k - 1; break; }
     float xc1 = cand ? dots[2 + 2 * (cand - 1)] : dots[1];
     float xc0 = dots[32 + 2 * cand], xc2 = dots[33 + 2 * cand];
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS + 3] = T; dbg[RN_DBG_DOTS + 4] = xc0; dbg[RN_DBG_DOTS + 5] = xc1; dbg[RN_DBG_DOTS + 6] = xc2; }
@@ -794,16 +870,21 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
   }
   __syncthreads();
-  // log-energy follower + total energy: 32 serial steps, evaluated uniformly
+  // log-energy follower + total energy: 32 serial steps, evaluated uniformly.  The reference forms
+  // follow-1.5 in double and rounds the selected maximum to float (src/denoise.c:381-386); follow-1.5 is
+  // exact in double, rounding is monotonic and the other operands are floats, so
+  // (float)max(follow-1.5, b) == max(follow-1.5f, b): the whole recurrence stays in float, same bits.
   float E = 0;
   {
     float logMax = -2, follow = -2;
     for (int i = 0; i < RN_NB_BANDS; i++) {
       float ly = Ly[i];
-      double t = ((double)follow - 1.5 > (double)ly) ? (double)follow - 1.5 : (double)ly;
-      ly = (float)(((double)(logMax - 7) > t) ? (double)(logMax - 7) : t);
+      const float fd = follow - 1.5f;
+      const float t = (fd > ly) ? fd : ly;
+      const float lm7 = logMax - 7;
+      ly = (lm7 > t) ? lm7 : t;
       logMax = (logMax > ly) ? logMax : ly;
-      follow = (float)(((double)follow - 1.5 > (double)ly) ? (double)follow - 1.5 : (double)ly);
+      follow = (fd > ly) ? fd : ly;
       E += Ex[i];
       if (lane == 0) Ly[i] = ly;
     }

@@ -542,6 +542,7 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   b->model = model;
   b->device = device;
   b->n = n_streams;
+  b->nn_path = (n_streams >= 16 && rn_nn_mfma_available()) ? 1 : 0;  // same bits either way; MFMA tiles hold 16 streams
   if (model_on_device(model, device, b->m) || tables_for_device(device, b->tb)) {
     delete b;
     return nullptr;

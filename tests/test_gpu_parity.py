@@ -286,8 +286,8 @@ def test_device_resident_path_with_torch_stream(model, blob_default):
 
 
 # ---- batched MFMA network path (rnnoise_batch_set_nn_path(b, 1)) -------------------------------
-@pytest.mark.parametrize("n", [4, 17, 64, 65])
-def test_mfma_path_bit_exact(model, blob_default, n):
+@pytest.mark.parametrize("n,path", [(4, 1), (17, 1), (64, 1), (65, 1), (17, 0), (65, 0)])
+def test_mfma_path_bit_exact(model, blob_default, n, path):
     """int8 MFMA on zero-filled dense tiles + f32 MFMA chains = same bits as the oracle, for tile
     counts that do and do not divide 16, with silent and non-silent streams mixed in one tile"""
     T = 40
@@ -297,7 +297,7 @@ def test_mfma_path_bit_exact(model, blob_default, n):
     pcm[20:26, 1::4] = 0      # others go silent mid-way (state must freeze, src/denoise.c:474)
     uniq = sorted({(i, s % 3 == 0, s % 4 == 1) for s, i in enumerate(ids)})
     b = capi.Batch(model, n)
-    b.set_nn_path(1)
+    assert b.set_nn_path(path) == (1 if n >= 16 else 0)   # documented default: MFMA from one full tile up
     out, vad, gains = b.process(pcm)
     cache = {}
     for s, i in enumerate(ids):
@@ -319,7 +319,7 @@ def test_mfma_and_vector_paths_agree_on_golden(model):
     streams = (0, 1, 159, 4095)
     pcm = synth.batch_pcm(streams, 400, lead_silence=5)
     b = capi.Batch(model, 4)
-    b.set_nn_path(1)
+    assert b.set_nn_path(1) == 0          # small batches default to the vector path (covered by the digest test above)
     got = gpu_run(b, pcm)
     for i, s in enumerate(streams):
         assert_bits_equal(got["gains"][:, i], g[f"s{s}_gains"], "gains")

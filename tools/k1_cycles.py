@@ -5,8 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rnnoise_amd import capi, synth
-NAMES = ["load", "biquad+wb", "win+FFT(X)+Ex", "downsample..FIR", "coarse xcorr", "coarse scan", "fine xcorr",
-         "fine scan", "doubling dots", "yy_lookup", "decide+3dots", "P FFT+Ep+Exp+feat"]
+NAMES = ["load", "-", "win+FFT(X)+Ex", "downsample+FIR", "coarse xcorr", "coarse scan", "fine xcorr",
+         "fine select", "doubling dots", "Syy+yy sweeps", "decide", "P FFT+Ep+Exp+feat"]
 blob = lzma.decompress(open(os.path.join(ROOT, "tests/golden/default.blob.xz"), "rb").read())
 m = capi.Model(blob)
 for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
