@@ -30,24 +30,27 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b) {  // src/_kiss_fft_guts.h:101
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.r + b.r, a.i + b.i}; }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i}; }
 
-// digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346 on factors {5,192,3,64,4,16,4,4,4,1})
-__device__ __forceinline__ int bitrev960_calc(int i) {
-  int j0 = i % 5, q = i / 5;
-  int j1 = q % 3; q /= 3;
-  int j2 = q & 3, j3 = (q >> 2) & 3, j4 = q >> 4;
-  return j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4;
-}
-// the same permutation from a 960-entry u16 table built on the host (one cached load instead of ~15 VALU)
+// The FFT work area is PADDED: logical element i lives at FPAD(i) = i + 2*(i/16), i.e. 16 bytes of padding
+// after every 128 bytes.  Unpadded, the two middle radix-4 stages read elements 16*i+j / 64*i+j (j < 4 /
+// j < 16) with the lanes of a wave spread over i, a 128-byte stride that lands on 8 (resp. 16) of the 64
+// LDS banks -- 16-way / 4-way conflicts on every access, and all 16 waves of a CU run the FFT at the
+// same time.  With the padding every stage spreads its 64 lanes evenly over the banks.
+#define FPAD(i) ((i) + 2 * ((i) >> 4))
+#define RN_FFT_PADDED (RN_WINDOW_SIZE + 2 * (RN_WINDOW_SIZE / 16))  // 1080 complex
+
+// digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346 on factors {5,192,3,64,4,16,4,4,4,1}),
+// from a 960-entry u16 table built on the host that already holds the PADDED position
 #define bitrev960(i) ((int)tb.bitrev[(i)])
 
-// In-place 960-point forward FFT on LDS data already scaled by 1/960 and digit-reversed
+// In-place 960-point forward FFT on LDS data already scaled by 1/960, digit-reversed and padded
 // (src/kiss_fft.c:518-564 stage order 4,4,4,3,5; butterflies :101-306).  Butterflies of a
 // stage are independent, so lanes take them round-robin; each butterfly is the reference's
-// exact expression tree.
+// exact expression tree.  A butterfly's elements are m apart: within one 16-group for m = 1, 4 and
+// whole groups apart otherwise, so the padded distance is a constant (18 per 16, 72 per 64, 216 per 192).
 __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
   __syncthreads();
   for (int b = lane; b < 240; b += WAVE) {  // radix-4, m=1, twiddle-free (:112-131)
-    cpx *p = F + 4 * b;
+    cpx *p = F + 4 * b + 2 * (b >> 2);
     cpx a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
     cpx s0 = csub(a0, a2), f0 = cadd(a0, a2), s1 = cadd(a1, a3);
     cpx f2 = csub(f0, s1);
@@ -61,19 +64,21 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
   __syncthreads();
 #pragma unroll
   for (int stage = 0; stage < 2; stage++) {  // radix-4: (m=4, fstride 60), (m=16, fstride 15) (:141-165)
-    const int m = stage ? 16 : 4, mm = 4 * m, fs = stage ? 15 : 60;
+    const int m = stage ? 16 : 4, fs = stage ? 15 : 60;
+    const int pm = stage ? 18 : 4;    // padded distance of m elements
+    const int pmm = stage ? 72 : 18;  // padded distance of 4*m elements
     for (int b = lane; b < 240; b += WAVE) {
       int i = b / m, j = b % m;
-      cpx *p = F + mm * i + j;
-      cpx s0 = cmul(p[m], tw[fs * j]);
-      cpx s1 = cmul(p[2 * m], tw[2 * fs * j]);
-      cpx s2 = cmul(p[3 * m], tw[3 * fs * j]);
+      cpx *p = F + pmm * i + j;
+      cpx s0 = cmul(p[pm], tw[fs * j]);
+      cpx s1 = cmul(p[2 * pm], tw[2 * fs * j]);
+      cpx s2 = cmul(p[3 * pm], tw[3 * fs * j]);
       cpx s5 = csub(p[0], s1), f0 = cadd(p[0], s1);
       cpx s3 = cadd(s0, s2), s4 = csub(s0, s2);
-      p[2 * m] = csub(f0, s3);
+      p[2 * pm] = csub(f0, s3);
       p[0] = cadd(f0, s3);
-      p[m] = {s5.r + s4.i, s5.i - s4.r};
-      p[3 * m] = {s5.r - s4.i, s5.i + s4.r};
+      p[pm] = {s5.r + s4.i, s5.i - s4.r};
+      p[3 * pm] = {s5.r - s4.i, s5.i + s4.r};
     }
     __syncthreads();
   }
@@ -81,29 +86,29 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
     const float epi3i = tw[5 * 64].i;
     for (int b = lane; b < 320; b += WAVE) {
       int i = b >> 6, j = b & 63;
-      cpx *p = F + 192 * i + j;
-      cpx s1 = cmul(p[64], tw[5 * j]);
-      cpx s2 = cmul(p[128], tw[10 * j]);
+      cpx *p = F + 216 * i + FPAD(j);
+      cpx s1 = cmul(p[72], tw[5 * j]);
+      cpx s2 = cmul(p[144], tw[10 * j]);
       cpx s3 = cadd(s1, s2), s0 = csub(s1, s2);
       cpx f0 = p[0];
       cpx fm = {f0.r - s3.r * .5f, f0.i - s3.i * .5f};
       s0.r *= epi3i;
       s0.i *= epi3i;
       p[0] = cadd(f0, s3);
-      p[128] = {fm.r + s0.i, fm.i - s0.r};
-      p[64] = {fm.r - s0.i, fm.i + s0.r};
+      p[144] = {fm.r + s0.i, fm.i - s0.r};
+      p[72] = {fm.r - s0.i, fm.i + s0.r};
     }
     __syncthreads();
   }
   {  // radix-5, m=192, fstride 1 (:269-302)
     const cpx ya = tw[192], yb = tw[384];
     for (int j = lane; j < 192; j += WAVE) {
-      cpx *p = F + j;
+      cpx *p = F + FPAD(j);
       cpx s0 = p[0];
-      cpx s1 = cmul(p[192], tw[j]);
-      cpx s2 = cmul(p[384], tw[2 * j]);
-      cpx s3 = cmul(p[576], tw[3 * j]);
-      cpx s4 = cmul(p[768], tw[4 * j]);
+      cpx s1 = cmul(p[216], tw[j]);
+      cpx s2 = cmul(p[432], tw[2 * j]);
+      cpx s3 = cmul(p[648], tw[3 * j]);
+      cpx s4 = cmul(p[864], tw[4 * j]);
       cpx s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
       cpx s5, s6, s11, s12;
       p[0] = {s0.r + (s7.r + s8.r), s0.i + (s7.i + s8.i)};
@@ -111,14 +116,14 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
       s5.i = s0.i + (s7.i * ya.r + s8.i * yb.r);
       s6.r = s10.i * ya.i + s9.i * yb.i;
       s6.i = -(s10.r * ya.i + s9.r * yb.i);
-      p[192] = csub(s5, s6);
-      p[768] = cadd(s5, s6);
+      p[216] = csub(s5, s6);
+      p[864] = cadd(s5, s6);
       s11.r = s0.r + (s7.r * yb.r + s8.r * ya.r);
       s11.i = s0.i + (s7.i * yb.r + s8.i * ya.r);
       s12.r = s9.i * ya.i - s10.i * yb.i;
       s12.i = s10.r * yb.i - s9.r * ya.i;
-      p[384] = cadd(s11, s12);
-      p[576] = csub(s11, s12);
+      p[432] = cadd(s11, s12);
+      p[648] = csub(s11, s12);
     }
     __syncthreads();
   }
@@ -131,15 +136,19 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
 // k's sequence is contiguous (hi part of bin -> Q[eband[b+1]+bin], lo part -> Q[eband[b]+bin]); then
 // lane k < 34 adds its sequence in order.  Padding steps add +0.0f, which changes no bit.
 // Q: LDS scratch of >= 864 floats; sums: LDS scratch [34].
+// XPAD / PPAD: the operand is an FFT work area (padded layout) rather than a plain array
+template <bool XPAD, bool PPAD>
 __device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float *Q, float *sums,
                                 const RnTablesDev &tb, int lane) {
-  for (int bin = lane; bin < 400; bin += WAVE) {
+#pragma unroll
+  for (int t = 0; t < 7; t++) {  // 400 = 6.25 x 64; constant trip count so that the table / HBM loads overlap
+    const int bin0 = lane + WAVE * t, bin = bin0 < 400 ? bin0 : 399;
     const int b = tb.band_of_bin[bin];
     const float frac = tb.band_frac[bin];
-    const cpx x = X[bin], y = P[bin];
+    const cpx x = X[XPAD ? FPAD(bin) : bin], y = P[PPAD ? FPAD(bin) : bin];
     float tmp = x.r * y.r;
     tmp += x.i * y.i;
-    Q[c_eband[b + 1] + bin] = frac * tmp;
+    Q[c_eband[b + 1] + bin] = frac * tmp;  // lanes past the end redo bin 399 with the same values: no branch
     Q[c_eband[b] + bin] = (1 - frac) * tmp;
   }
   __syncthreads();
@@ -529,8 +538,8 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
 
 // One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared
 // (float offsets, the SCR_* constants below):
-//   FFT phases   : F = [0,1920) (960 complex); the band products Q live in [1000,1864), above the 481
-//                  bins that matter; small per-frame vectors in [2392,2560)
+//   FFT phases   : F = [0,2160) (960 complex, padded layout); the band products Q live in [1084,1948),
+//                  above the 481 bins that matter; small per-frame vectors in [2392,2560)
 //   coarse search: xlp [0,864) | squares [864,1252) | y4 [1296,1728) | interleaved pairs Z [1728,2334)
 //                  during the 147 chains, then running energies [1728,1876) and xcorr [2028,2175)
 //   fine search  : xlp | reversed squares -> yy_lookup [864,1728) | energy increments -> Syy [1731,2028)
@@ -582,7 +591,7 @@ struct AnalysisLds {
 #define SCR_XC 2028   // [296]  xcorr[] of pitch_search
 #define SCR_ZERO 2324 // [4]
 #define SCR_DOTS 2120 // [64]
-#define SCR_Q 1000    // [864]  band products
+#define SCR_Q 1084    // [864]  band products (above the padded bins 0..480 = floats [0,1082))
 #define SCR_MISC 2392 // sums[40] | Ex[32] | Ep[32] | Exp[32] | Ly[32]
 
 // ---------------------------------------------------------------------------------------------
@@ -615,31 +624,35 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   CLK_TAP(0);
   CLK_TAP(1);
   // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
-  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+#pragma unroll 5
+  for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
+    const int i = lane + WAVE * t;
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
     float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i) * w;
     F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
   fft960_lds(F, tw, lane);
   if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[i] = {0.f, 0.f};
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[FPAD(i)] = {0.f, 0.f};
     __syncthreads();
   }
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = F[i];
+    cpx v = F[FPAD(i)];
     gX[2 * i] = v.r;
     gX[2 * i + 1] = v.i;
   }
-  band_accumulate(Ex, F, F, Qs, sums, tb, lane);
+  band_accumulate<true, true>(Ex, F, F, Qs, sums, tb, lane);
 
   CLK_TAP(2);  // window + FFT(X) + Ex
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
-  for (int i = lane; i < 864; i += WAVE) {
-    float v;
-    if (i == 0) v = .5f * (.5f * (PB(1)) + PB(0));
-    else v = .5f * (.5f * (PB(2 * i - 1) + PB(2 * i + 1)) + PB(2 * i));
-    xlp[i] = v;
+#pragma unroll 7
+  for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
+    const int i0 = lane + WAVE * t, i = i0 < 864 ? i0 : 863;  // clamp, not a branch
+    const float a = PB(i ? 2 * i - 1 : 0), b = PB(2 * i), c = PB(2 * i + 1);
+    float v = .5f * (.5f * (a + c) + b);
+    if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
+    xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
   }
   __syncthreads();
   // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
@@ -835,24 +848,32 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 
   CLK_TAP(10);  // doubling decisions + 3 final dots
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
-  float dctc[RN_NB_BANDS];  // this lane's DCT column, requested now, consumed after the FFT
-#pragma unroll
-  for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
-  for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+#pragma unroll 5
+  for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
+    const int i = lane + WAVE * t;
     float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
     float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i) * w;
     F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
   }
-  fft960_lds(F, tw, lane);
+  {
+    // a second, opaque copy of the pointer: otherwise the per-lane twiddles of the first FFT are kept alive
+    // (and spilled to scratch) across the whole pitch stage instead of being re-read from L1/L2
+    const cpx *tw2 = tw;
+    asm volatile("" : "+s"(tw2));
+    fft960_lds(F, tw2, lane);
+  }
   float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
   for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = F[i];
+    cpx v = F[FPAD(i)];
     gP[2 * i] = v.r;
     gP[2 * i + 1] = v.i;
   }
-  band_accumulate(Ep, F, F, Qs, sums, tb, lane);
+  float dctc[RN_NB_BANDS];  // this lane's DCT column, requested now, consumed after the band energies
+#pragma unroll
+  for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
+  band_accumulate<true, true>(Ep, F, F, Qs, sums, tb, lane);
   // X is read back from HBM/L2 (this block wrote it; the barriers since then make it visible)
-  band_accumulate(Exp, reinterpret_cast<const cpx *>(gX), F, Qs, sums, tb, lane);
+  band_accumulate<false, true>(Exp, reinterpret_cast<const cpx *>(gX), F, Qs, sums, tb, lane);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
@@ -923,10 +944,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     fft960_lds(F, tw, lane);
     for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) cm[i] = cx[i];
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[i] = {0.f, 0.f};
+    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[FPAD(i)] = {0.f, 0.f};
     __syncthreads();
     float *Ey = Ep;  // Ep already went to HBM
-    band_accumulate(Ey, F, F, Qs, sums, tb, lane);
+    band_accumulate<true, true>(Ey, F, F, Qs, sums, tb, lane);
     if (lane < RN_NB_BANDS) {
       float gt = (float)sqrt(((double)Ey[lane] + 1e-3) / ((double)Ex[lane] + 1e-3));
       if (gt > 1) gt = 1;
@@ -955,7 +976,7 @@ rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnT
 
 
 struct SynthLds {
-  cpx F[RN_WINDOW_SIZE];  // inverse-FFT work area; band products before that
+  cpx F[RN_FFT_PADDED];  // inverse-FFT work area (padded layout); band products before that
   float misc[192];
 };
 
@@ -1107,8 +1128,9 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   for (int j = 0; j < 8; j++) {
     const int i = lane + WAVE * j;
     if (i < RN_FRAME_SIZE) {
-      float lo = (float)RN_WINDOW_SIZE * L.F[(RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE].r;  // x[i]
-      float hi = (float)RN_WINDOW_SIZE * L.F[RN_FRAME_SIZE - i].r;                      // x[480+i], window index 479-i
+      const int ilo = (RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE, ihi = RN_FRAME_SIZE - i;
+      float lo = (float)RN_WINDOW_SIZE * L.F[FPAD(ilo)].r;  // x[i]
+      float hi = (float)RN_WINDOW_SIZE * L.F[FPAD(ihi)].r;  // x[480+i], window index 479-i
       lo *= wlo[j];
       hi *= whi[j];
       o[i] = lo + smv[j];

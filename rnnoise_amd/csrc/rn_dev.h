@@ -32,7 +32,7 @@ struct RnTablesDev {
   const float *dct;           // [32*32] src/rnnoise_tables.c:669
   const float *twiddles;      // [960*2] src/rnnoise_tables.c:77
   const float *band_frac;     // [400]   (float)j/band_size of each bin (src/denoise.c:100)
-  const uint16_t *bitrev;     // [960]   digit reversal of the 5.3.4.4.4 FFT (src/rnnoise_tables.c:10, by formula)
+  const uint16_t *bitrev;     // [960]   digit reversal of the 5.3.4.4.4 FFT (src/rnnoise_tables.c:10, by formula), padded position
   const uint8_t *band_of_bin; // [400]   band index i with eband[i] <= bin < eband[i+1]
   const uint32_t *rcp_lut;    // [2048]  x86 rcpps stand-in (oracle/rcp_capture.c)
   double dct_scale;           // sqrt(2./22), src/denoise.c:168

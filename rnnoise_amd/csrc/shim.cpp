@@ -289,7 +289,8 @@ int tables_for_device(int device, RnTablesDev &out) {
   std::vector<uint16_t> bitrev(RN_WINDOW_SIZE);
   for (int i = 0; i < RN_WINDOW_SIZE; i++) {  // digit reversal for radices 5,3,4,4,4 (src/kiss_fft.c:314-346)
     int j0 = i % 5, j1 = (i / 5) % 3, j2 = (i / 15) % 4, j3 = (i / 60) % 4, j4 = i / 240;
-    bitrev[i] = (uint16_t)(j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4);
+    const int r = j0 * 192 + j1 * 64 + j2 * 16 + j3 * 4 + j4;
+    bitrev[i] = (uint16_t)(r + 2 * (r >> 4));  // position in the padded FFT work area (FPAD, dsp_kernels.hip)
   }
   for (int i = 0; i < RN_FRAME_SIZE; i++) {
     double a = .5 * M_PI * (i + .5) / RN_FRAME_SIZE;
