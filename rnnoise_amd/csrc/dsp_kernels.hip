@@ -244,29 +244,20 @@ __device__ __forceinline__ void best_pitch_select(const float *xcorr, const floa
 }
 
 // src/pitch.c:44-102 (float build), restructured so that only the genuinely serial part stays
-// serial:  (1) all lanes square y[] (each product rounded once, as in the reference) and form
-// d[i] = y[i+len]^2 - y[i]^2;  (2) the running energy Syy -- a float recurrence with a clamp, hence
-// order-bound -- is swept once, 4 steps per LDS transaction, leaving Syy-before-step-i in syy[i];
+// serial:  (1) all lanes form d[i] = y[i+len]^2 - y[i]^2 (each product rounded once, as in the
+// reference);  (2) the running energy Syy -- a float recurrence with a clamp, hence order-bound -- is
+// swept once from the start value Syy0 = 1 + sum_{j<len} y[j]^2 (computed by the caller inside a
+// dot-product pass), 4 steps per LDS transaction, leaving Syy-before-step-i in syy[i];
 // (3) best_pitch_select.  Used for the coarse (4x decimated) search; the fine search shares its sweep
-// with yy_lookup (energy_sweeps below).
-// sq: scratch >= len + max_pitch (+3) floats; syy: scratch >= max_pitch rounded up to 4.
-__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, float *sq, float *syy,
+// with yy_lookup (energy_sweeps below).  syy: scratch >= max_pitch rounded up to 4.
+__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, float Syy0, float *syy,
                                 int &bp0, int &bp1, int lane) {
   const int mp4 = (max_pitch + 3) & ~3;
-  for (int j = lane; j < len + mp4; j += WAVE) {
-    const float v = (j < len + max_pitch) ? y[j] : 0.f;
-    sq[j] = v * v;
+  for (int i = lane; i < mp4; i += WAVE) {
+    const float a = (i + len < len + max_pitch) ? y[i + len] : 0.f, b = y[i];
+    syy[i] = a * a - b * b;
   }
-  __syncthreads();
-  for (int i = lane; i < mp4; i += WAVE) syy[i] = sq[i + len] - sq[i];
-  float Syy = 1;
-  for (int j = 0; j < len; j += 4) {  // len is 240
-    const float4 v = *reinterpret_cast<const float4 *>(sq + j);
-    Syy = Syy + v.x;
-    Syy = Syy + v.y;
-    Syy = Syy + v.z;
-    Syy = Syy + v.w;
-  }
+  float Syy = Syy0;
   __syncthreads();
   for (int i = 0; i < mp4; i += 4) {
     const float4 d = *reinterpret_cast<const float4 *>(syy + i);
@@ -285,17 +276,18 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
 // The two long running-energy recurrences of the pitch stage, swept TOGETHER (lane 0 / lane 1 of the
 // same instructions; a one-lane VALU instruction costs as much issue time as a 64-lane one):
 //   lane 0: Syy of the fine find_best_pitch (src/pitch.c:56-61,93-94; y = x_lp, len 480, 294 lags)
-//           init 1 + sum_{j<480} y[j]^2, then Syy = max(1, Syy + (y[i+480]^2 - y[i]^2))
+//           from syy0 = 1 + sum_{j<480} y[j]^2:  Syy = max(1, Syy + (y[i+480]^2 - y[i]^2))
 //   lane 1: yy_lookup of remove_doubling (src/pitch.c:441-456; x = x_lp+384, N 480, 384 periods)
-//           init xx = sum_{j<480} x[j]^2, then yy = (yy + x[-i]^2) - x[N-i]^2 (clamped copy stored)
+//           from xx = sum_{j<480} x[j]^2:  yy = (yy + x[-i]^2) - x[N-i]^2 (clamped copy stored)
+// (both start values come out of the fine cross-correlation pass, as two extra chains).
 // One step is  s = max(lo, (s + A) - B)  with (A, B, lo) = (d[i], 0, 1) for lane 0 and
 // (x[-i]^2, x[N-i]^2, -inf) for lane 1; x - 0 and max(-inf, x) change no bit.
-// rsq[k] = x_lp[863-k]^2 (864 floats): reversed, so that both init sums walk DOWN it and both of lane 1's
-// sweep operands walk UP it: A_i = rsq[479+i], B_i = rsq[i-1].  Results overwrite the A operand just
-// consumed: afterwards  Syy-before-lag-i = D[i-1] (D[-1] = init)  and  yy_lookup[i] = rsq[479+i]
-// (rsq[479] = xx), clamped at 0 by a parallel pass.  D: 16-byte aligned, D[-1..295]; zero4: 4 floats.
-// Returns xx.
-__device__ __forceinline__ float energy_sweeps(const float *xlp, float *rsq, float *D, float *zero4, int lane) {
+// rsq[k] = x_lp[863-k]^2 (864 floats): reversed, so that both of lane 1's operands walk UP it:
+// A_i = rsq[479+i], B_i = rsq[i-1].  Results overwrite the A operand just consumed: afterwards
+// Syy-before-lag-i = D[i-1] (D[-1] = syy0)  and  yy_lookup[i] = rsq[479+i] (rsq[479] = xx), clamped
+// at 0 by a parallel pass.  D: 16-byte aligned, D[-1..295]; zero4: 4 floats.
+__device__ __forceinline__ void energy_sweeps(const float *xlp, float *rsq, float *D, float *zero4, float syy0,
+                                              float xx, int lane) {
   for (int k = lane; k < 864; k += WAVE) {
     const float v = xlp[863 - k];
     rsq[k] = v * v;
@@ -306,22 +298,10 @@ __device__ __forceinline__ float energy_sweeps(const float *xlp, float *rsq, flo
   }
   if (lane < 4) zero4[lane] = 0.f;
   __syncthreads();
-  float s = (lane == 0) ? 1.f : 0.f;
+  if (lane == 0) D[-1] = syy0;
+  if (lane == 1) rsq[479] = xx;
   {
-    const float *p = rsq + ((lane == 0) ? 860 : 476);
-    for (int j = 0; j < 480; j += 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(p - j);
-      s = s + v.w;
-      s = s + v.z;
-      s = s + v.y;
-      s = s + v.x;
-    }
-  }
-  const float xx = lane_bcast(s, 1);
-  __syncthreads();  // every lane has finished reading rsq[479] / the init operands
-  if (lane == 0) D[-1] = s;
-  if (lane == 1) rsq[479] = s;
-  {
+    float s = (lane == 0) ? syy0 : xx;
     float *pa = (lane == 0) ? D : rsq + 480;
     const float *pb = (lane == 0) ? zero4 : rsq;
     const int sb = (lane == 0) ? 0 : 4;
@@ -344,7 +324,6 @@ __device__ __forceinline__ float energy_sweeps(const float *xlp, float *rsq, flo
   __syncthreads();
   for (int i = 1 + lane; i <= 384; i += WAVE) rsq[479 + i] = fmaxf(0.f, rsq[479 + i]);  // MAX32(0, yy)
   __syncthreads();
-  return xx;
 }
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
@@ -500,11 +479,13 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
 }
 
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
-// x 16-byte aligned (identical for all lanes), y arbitrary.  The next 8 operand pairs are fetched
+// x 16-byte aligned, y arbitrary; both may differ per lane.  The next 8 operand pairs are fetched
 // from LDS while the current 8 are being added, so the LDS round trip is off the chain.
+// s0 is the chain's start value: a lane with x == y and s0 = 1 computes a find_best_pitch start
+// energy 1 + sum y[j]^2 (src/pitch.c:56-61) in the same instructions as the real dot products.
 #define OPAQUE(v) asm("" : "+v"(v))
-__device__ __forceinline__ float chain_dot8(const float *x, const float *y, int n) {
-  float s = 0;
+__device__ __forceinline__ float chain_dot8(const float *x, const float *y, int n, float s0 = 0.f) {
+  float s = s0;
   float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
   float ya[8];
 #pragma unroll
@@ -540,7 +521,7 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
 // (float offsets, the SCR_* constants below):
 //   FFT phases   : F = [0,2160) (960 complex, padded layout); the band products Q live in [1084,1948),
 //                  above the 481 bins that matter; small per-frame vectors in [2392,2560)
-//   coarse search: xlp [0,864) | squares [864,1252) | y4 [1296,1728) | interleaved pairs Z [1728,2334)
+//   coarse search: xlp [0,864) | y4 [1296,1728) | interleaved pairs Z [1728,2334)
 //                  during the 147 chains, then running energies [1728,1876) and xcorr [2028,2175)
 //   fine search  : xlp | reversed squares -> yy_lookup [864,1728) | energy increments -> Syy [1731,2028)
 //                  | xcorr [2028,2324) | 4 zeros [2324,2328); the 64 doubling dots reuse [2120,2184)
@@ -583,7 +564,7 @@ struct AnalysisLds {
   float a[2560];
 };
 #define SCR_XLP 0
-#define SCR_SQ 864    // [388]  squares of y4 (coarse search); [864] reversed squares of xlp, later yy_lookup
+#define SCR_SQ 864    // [864]  fine search: reversed squares of xlp, later yy_lookup
 #define SCR_Y4 1296   // [432]  4x-decimated signal (coarse search only)
 #define SCR_Z 1728    // [606]  {y4[j], y4[j+64]} pairs for the packed coarse chains
 #define SCR_SYY 1728  // [148]  running energies of the coarse find_best_pitch
@@ -691,45 +672,53 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC;
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
   for (int j = lane; j < 432; j += WAVE) y4[j] = xlp[2 * j];
+  float syy0_coarse;
   {
     v2f *Z = reinterpret_cast<v2f *>(scr + SCR_Z);
     for (int j = lane; j < 303; j += WAVE) Z[j] = v2f{xlp[2 * j], xlp[2 * j + 128]};
     __syncthreads();
     // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
     const v2f p = chain_dot8_x2(y4 + 192, Z + lane, 240);
+    // lanes 0..18: lags 128..146; lane 19: the start energy 1 + sum y4[j]^2 of the coarse find_best_pitch
     float q = 0;
-    if (lane < 147 - 128) q = chain_dot8(y4 + 192, y4 + lane + 128, 240);
+    if (lane < 20) q = chain_dot8(lane < 19 ? y4 + 192 : y4, lane < 19 ? y4 + lane + 128 : y4, 240, lane < 19 ? 0.f : 1.f);
     __syncthreads();  // Z is dead; xcorr goes into its area
     xc[lane] = p.x;
     xc[lane + 64] = p.y;
     if (lane < 147 - 128) xc[lane + 128] = q;
+    syy0_coarse = lane_bcast(q, 19);
   }
   __syncthreads();
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
-  find_best_pitch(xc, y4, 240, 147, scr + SCR_SQ, scr + SCR_SYY, bp0, bp1, lane);
+  find_best_pitch(xc, y4, 240, 147, syy0_coarse, scr + SCR_SYY, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
   if (dbg) {
     for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
   }
   __syncthreads();
-  // running energies of the fine search and of remove_doubling, one shared sweep (y4 / squares are dead)
-  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
-  const float xx = energy_sweeps(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
-  const float *yyl = rsq + 479;  // yy_lookup[i], i = 0..384
-  CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps
   for (int i = lane; i < 294; i += WAVE) xc[i] = 0;
   __syncthreads();
-  if (lane < 10) {
+  float xx, syy0_fine;
+  {  // lanes 0..9: the fine lags; lane 10: xx = <x, x> of remove_doubling; lane 11: 1 + sum x_lp[j]^2 (fine Syy start)
     int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
-    if (c >= 0 && c < 294) {
-      float sum = chain_dot8(xlp + 384, xlp + c, 480);
-      xc[c] = (-1 > sum) ? -1 : sum;
-    }
+    const bool lag = lane < 10 && c >= 0 && c < 294;
+    float sum = 0;
+    if (lag || lane == 10 || lane == 11)
+      sum = chain_dot8(lane == 11 ? xlp : xlp + 384, lag ? xlp + c : (lane == 11 ? xlp : xlp + 384), 480,
+                       lane == 11 ? 1.f : 0.f);
+    if (lag) xc[c] = (-1 > sum) ? -1 : sum;
+    xx = lane_bcast(sum, 10);
+    syy0_fine = lane_bcast(sum, 11);
   }
   __syncthreads();
-  CLK_TAP(6);  // fine xcorr
+  CLK_TAP(6);  // fine xcorr (+ the two start energies)
+  // running energies of the fine search and of remove_doubling, one shared sweep (y4 is dead)
+  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
+  energy_sweeps(xlp, rsq, Dsyy, scr + SCR_ZERO, syy0_fine, xx, lane);
+  const float *yyl = rsq + 479;  // yy_lookup[i], i = 0..384
+  CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps
   best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch selection
   int offset = 0;
