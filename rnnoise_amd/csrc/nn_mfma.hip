@@ -25,6 +25,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define NWAVES 8       // 2 waves per SIMD: one wave's weight loads / epilogue overlap the other's MFMAs
 #define NTHREADS (64 * NWAVES)
 #define KT 6           // 384 / 64 k-tiles of every int8 layer
+#define CHUNK 128      // inputs per staged chunk of the dense_out / vad chains
+#define CH_STRIDE 132  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
 
 // ---- x86-profile activations (same arithmetic as nn_kernels.hip; LUT staged in LDS) ----
 __device__ __forceinline__ float rcp_x86(float x, const uint32_t *lut) {
@@ -71,9 +73,14 @@ __device__ __forceinline__ int frag_off(int n, int k) { return (((k >> 6) * 64 +
 
 struct MfmaLds {
   uint32_t lut[2048];             // rcpps table
-  float tmp1[TS][197];            // conv1 input [t-2|t-1|t], padded row
-  int8_t xq[2][KT * 64 * 16];     // quantised layer input, B-fragment order (double buffer)
-  int8_t hq[KT * 64 * 16];        // quantised recurrent state
+  union {
+    struct {
+      float tmp1[TS][197];          // conv1 input [t-2|t-1|t], padded row
+      int8_t xq[2][KT * 64 * 16];   // quantised layer input, B-fragment order (double buffer)
+      int8_t hq[KT * 64 * 16];      // quantised recurrent state
+    };
+    float stage[2][TS][CH_STRIDE];  // dense_out / vad phase: f32 activations, 128 inputs per chunk, double buffer
+  };
 };
 
 // one int8 output-row tile: 6 MFMAs over K=384, A straight from the pre-swizzled weights
@@ -227,54 +234,76 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   // ---- dense_out (1536 -> 32, f32 MFMA chains, waves 0-1) and vad_dense (wave 2, lane = stream) ----
   // cat = [conv2 out | gru1 | gru2 | gru3] (src/rnn.c:53-55); silent streams are computed on
   // their unchanged state and discarded.
-  // Both loops are dependent chains fed from L2; operands for the next 8 steps are requested
-  // before the current 8 are consumed so that the chain, not the memory latency, sets the pace.
-  if (wave < 2) {
-    v4f acc = {0, 0, 0, 0};
-    const float *fw = m.dense_out.fw + 16 * wave + n;
-    auto lda = [&](int t) { return fw[(size_t)(4 * t + gq) * RN_NB_BANDS]; };  // k = 4t + gq runs over all 1536 inputs
-    auto ldb = [&](int t) {
-      const int seg = t / 96, k = 4 * (t - 96 * seg) + gq;
-      const float *src = (seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) + (size_t)sn * RN_GRU;
-      return src[k];
+  // The chains are serial over the 1536 inputs.  Their activation operand is staged through LDS in
+  // chunks of 128 inputs by the whole workgroup (one coalesced 16-byte load per thread and chunk, issued
+  // a full chunk ahead and parked in a register), because fetched straight from the per-stream rows every
+  // chain step costs 16 scattered L1 accesses -- and the vector L1 is what this kernel saturates first.
+  // The dense weights stay in L2 (64-byte rows, 8 steps ahead).
+  {
+    const int pq = tid >> 5, pc = (tid & 31) << 2;              // producer role: stream pq, floats pc..pc+3 of a chunk
+    const int ps = (s0 + pq < N) ? s0 + pq : N - 1;
+    auto chunk_src = [&](int c) {                                // chunk c = inputs 128c .. 128c+127 of cat
+      const int seg = c / 3, k0 = (c - 3 * seg) * CHUNK;
+      return reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) +
+                                           (size_t)ps * RN_GRU + k0 + pc);
     };
-    float ca[8], cb[8];
+    constexpr int NCH = 4 * RN_GRU / CHUNK;  // 12
+    v4f park = *chunk_src(0);
+    *reinterpret_cast<v4f *>(&L.stage[0][pq][pc]) = park;  // xq / hq / tmp1 are dead: the last GRU barrier is behind us
+    park = *chunk_src(1);
+    v4f dacc = {0, 0, 0, 0};
+    float vacc = 0;
+    const float *fw = m.dense_out.fw + (size_t)gq * RN_NB_BANDS + 16 * (wave & 1) + n;  // element k = 4t+gq, t global
+    float ca[8];
+    if (wave < 2) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) { ca[u] = lda(u); cb[u] = ldb(u); }
-    for (int t0 = 0; t0 < 384; t0 += 8) {
-      const int tn = (t0 + 8 < 384) ? t0 + 8 : t0;
-      float na[8], nb[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { na[u] = lda(tn + u); nb[u] = ldb(tn + u); }
-#pragma unroll
-      for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u], cb[u], acc, 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
+      for (int u = 0; u < 8; u++) ca[u] = fw[(size_t)(4 * u) * RN_NB_BANDS];
     }
-    const int row0 = 16 * wave + 4 * gq;
-    const v4f bs = *reinterpret_cast<const v4f *>(m.dense_out.bias + row0);
-    v4f o;
+    __syncthreads();
+    for (int c = 0; c < NCH; c++) {
+      if (c + 1 < NCH) *reinterpret_cast<v4f *>(&L.stage[(c + 1) & 1][pq][pc]) = park;
+      if (c + 2 < NCH) park = *chunk_src(c + 2);
+      const float(*sx)[CH_STRIDE] = L.stage[c & 1];
+      if (wave < 2) {  // 32 MFMA steps: t = 32c + tt, k = 4t + gq
+        const float *bx = &sx[n][gq];
+        for (int t0 = 0; t0 < CHUNK / 4; t0 += 8) {
+          const int t = (CHUNK / 4) * c + t0;
+          const int tn = (t + 8 < 4 * RN_GRU / 4) ? t + 8 : t;
+          float na[8], cb[8];
 #pragma unroll
-    for (int r = 0; r < 4; r++) o[r] = live ? sigmoid_x86(acc[r] + bs[r], lut) : 0.f;
-    if (s0 + n < N) *reinterpret_cast<v4f *>(g.gains + (size_t)sn * RN_NB_BANDS + row0) = o;
-  } else if (wave == 2 && lane < TS) {
-    float acc = 0;
-    for (int seg = 0; seg < 4; seg++) {
-      const v4f *src = reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) +
-                                                     (size_t)sn * RN_GRU);
-      const v4f *w = reinterpret_cast<const v4f *>(m.vad_dense.fw + seg * RN_GRU);
-      v4f w0 = w[0], w1 = w[1], x0 = src[0], x1 = src[1];
-      for (int j = 0; j < RN_GRU / 4; j += 2) {
-        const int jn = (j + 2 < RN_GRU / 4) ? j + 2 : j;
-        const v4f nw0 = w[jn], nw1 = w[jn + 1], nx0 = src[jn], nx1 = src[jn + 1];
+          for (int u = 0; u < 8; u++) {
+            na[u] = fw[(size_t)(4 * (tn + u)) * RN_NB_BANDS];
+            cb[u] = bx[4 * (t0 + u)];
+          }
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc = acc + w0[e] * x0[e];  // unfused, src/vec_avx.h:732-736
+          for (int u = 0; u < 8; u++) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u], cb[u], dacc, 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc = acc + w1[e] * x1[e];
-        w0 = nw0; w1 = nw1; x0 = nx0; x1 = nx1;
+          for (int u = 0; u < 8; u++) ca[u] = na[u];
+        }
+      } else if (wave == 2 && lane < TS) {  // unfused mul-then-add, src/vec_avx.h:732-736
+        const v4f *w = reinterpret_cast<const v4f *>(m.vad_dense.fw + CHUNK * c);
+        const v4f *x = reinterpret_cast<const v4f *>(sx[lane]);
+#pragma unroll 4
+        for (int j = 0; j < CHUNK / 4; j++) {
+          const v4f wj = w[j], xj = x[j];
+#pragma unroll
+          for (int e = 0; e < 4; e++) vacc = vacc + wj[e] * xj[e];
+        }
       }
+      __syncthreads();
     }
-    if (s0 + n < N) g.vad[sn] = live ? sigmoid_x86(acc + m.vad_dense.bias[0], lut) : 0.f;
+    if (wave < 2) {
+      const int row0 = 16 * wave + 4 * gq;
+      const v4f bs = *reinterpret_cast<const v4f *>(m.dense_out.bias + row0);
+      v4f o;
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] = live ? sigmoid_x86(dacc[r] + bs[r], lut) : 0.f;
+      if (s0 + n < N) *reinterpret_cast<v4f *>(g.gains + (size_t)sn * RN_NB_BANDS + row0) = o;
+    } else if (wave == 2 && lane < TS) {
+      const int q = s0 + lane, sq = q < N ? q : N - 1;
+      const bool lv = q < N && !g.silence[sq];
+      if (q < N) g.vad[sq] = lv ? sigmoid_x86(vacc + m.vad_dense.bias[0], lut) : 0.f;
+    }
   }
   CLK_TAP(6);  // dense_out / vad (wave 0's view)
 }

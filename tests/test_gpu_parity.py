@@ -207,6 +207,29 @@ def test_full_size_batch_properties(model, blob_default):
     assert_bits_equal(b.export_state(4095), want["state"][15], "state of the last stream")
 
 
+def test_16384_stream_batch_properties(model, blob_default):
+    """16384 streams (4 network tiles per CU): replicated streams stay identical, a sample matches the
+    oracle bit for bit, and one stream starts silent (network skipped, state frozen) while its tile
+    neighbours run."""
+    N, T = 16384, 6
+    base = synth.batch_pcm(range(32), T)
+    base[:3, 21] = 0                       # silent for 3 frames
+    pcm = np.ascontiguousarray(np.tile(base, (1, N // 32, 1)))
+    b = capi.Batch(model, N)
+    out, vad, gains = b.process(pcm)
+    for k in range(0, N, 32):
+        assert np.array_equal(out[:, k:k + 32].view(np.uint32), out[:, :32].view(np.uint32)), f"tile at {k}"
+        assert np.array_equal(gains[:, k:k + 32].view(np.uint32), gains[:, :32].view(np.uint32)), f"tile at {k}"
+        assert np.array_equal(vad[:, k:k + 32].view(np.uint32), vad[:, :32].view(np.uint32)), f"tile at {k}"
+    want = oracle_run(blob_default, base)
+    assert want["silence"][:, 21].any()
+    assert_bits_equal(out[:, :32], want["out"], "pcm")
+    assert_bits_equal(gains[:, :32], want["gains"], "gains")
+    assert_bits_equal(vad[:, :32], want["vad"], "vad")
+    for s_ in (0, 15, 16, 21, 31):
+        assert_bits_equal(b.export_state(N - 32 + s_), want["state"][s_], f"state of stream {N - 32 + s_}")
+
+
 def test_state_export_import_round_trip_and_teacher_forcing(model, blob_default):
     pcm = synth.batch_pcm([5, 6], 40)
     b = capi.Batch(model, 2)
