@@ -208,9 +208,12 @@ def main():
 
     if rank == 0:
         sane = bool(torch.isfinite(d_out).all().item()) and float(d_vad.max().item()) > 0.0
-        per_kernel = {"analysis": ANALYSIS_BYTES, "network": W + NETWORK_STATE_BYTES, "synthesis": SYNTHESIS_BYTES}
+        # algorithmic HBM bytes per launch: per-stream traffic x streams; the weights are read from HBM at most
+        # once per launch, whatever the batch (every later tile finds them in L2 / Infinity Cache) -- the
+        # north_star's per-frame W figure is reported separately as weight_roofline
+        per_launch = {"analysis": ANALYSIS_BYTES * N, "network": W + NETWORK_STATE_BYTES * N, "synthesis": SYNTHESIS_BYTES * N}
         dom = max(("analysis", "network", "synthesis"), key=lambda k: kms[k])
-        ach = per_kernel[dom] * N / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         kname = f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel"
         line = {
             "metric": "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline",
@@ -226,7 +229,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname + (" (+rn_hp_kernel)" if dom == "analysis" else ""),
                          "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": measured_traffic(kname, N),
-                         "algorithmic_bytes_per_launch": per_kernel[dom] * N,
+                         "algorithmic_bytes_per_launch": per_launch[dom],
                          "kernel_ms": {k: round(kms[k], 4) for k in ("analysis", "network", "synthesis")}},
             "weight_roofline": {"W_bytes_per_frame": W, "frac": round(value * W / (a.gpus * HBM_PEAK), 5),
                                 "definition": "frames/s x W / (n_gpus x 8.0e12 B/s), north_star / SURVEY 8d"},

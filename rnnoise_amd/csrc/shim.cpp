@@ -27,6 +27,9 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
 
+// batches below this size run K1 on its own stream as well (3-stream schedule, see rnnoise_batch_process_device)
+#define RN_PIPE3_MAX_STREAMS 32768
+
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \
@@ -627,6 +630,11 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   //     double-buffered, so analysis(f) only has to wait for synthesis(f-2);
   //   * every other piece of state is touched by one kernel only, in frame order on its own stream.
   const bool pipelined = n_frames > 1;
+  // Once the batch fills every CU several times over, running K1 beside K2/K3 only makes them thrash each
+  // other (measured: 65,536 streams are 8 % faster with K1 back on the caller's stream); the latency-bound
+  // K0 stays on its side stream at every size.  RNNOISE_AMD_PIPE = 1 / 2 forces the 2- / 3-stream schedule.
+  static const int pipe_force = [] { const char *e = getenv("RNNOISE_AMD_PIPE"); return e ? atoi(e) : 0; }();
+  const bool side_k1 = pipelined && (pipe_force ? pipe_force >= 2 : b->n < RN_PIPE3_MAX_STREAMS);
   if (pipelined && !b->side) {
     HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
@@ -637,10 +645,10 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], hipEventDisableTiming));
     }
   }
-  hipStream_t sb = pipelined ? b->side : st, sc = pipelined ? b->side_hp : st;
+  hipStream_t sb = side_k1 ? b->side : st, sc = pipelined ? b->side_hp : st;
   if (pipelined) {  // B and C start after everything already queued on the caller's stream
     HIP_OK(hipEventRecord(b->ev_begin, st));
-    HIP_OK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
+    if (side_k1) HIP_OK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
     HIP_OK(hipStreamWaitEvent(b->side_hp, b->ev_begin, 0));
   }
   auto frame_group = [&](int f) {
@@ -663,7 +671,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     RnGroupDev g = frame_group(f);
     if (pipelined) {
       HIP_OK(hipStreamWaitEvent(sb, b->ev_hp[f & 7], 0));
-      if (f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 7], 0));
+      if (side_k1 && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 7], 0));
     }
     {
       ScopedEvent ev(b, sb, 0);
@@ -685,7 +693,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     } else {
       if (f + 3 < n_frames && highpass(f + 3)) return -1;
       if (f + 1 < n_frames && analysis(f + 1)) return -1;
-      HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 7], 0));
+      if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 7], 0));
     }
     {
       ScopedEvent ev(b, st, 1);
@@ -696,7 +704,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       ScopedEvent ev(b, st, 2);
       HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st));
     }
-    if (pipelined) HIP_OK(hipEventRecord(b->ev_k3[f & 7], st));
+    if (side_k1) HIP_OK(hipEventRecord(b->ev_k3[f & 7], st));
     b->launches += b->timing ? 1 : 0;
   }
   b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;

@@ -42,5 +42,5 @@ for N in [int(x) for x in sys.argv[1:]] or [4096, 65536]:
     k = b.kernel_ms()
     rest = dt - k["analysis"] - k["network"] - k["synthesis"]
     print(f"N={N}: step {dt:.4f} ms serial | K1 {k['analysis']:.4f}  K2 {k['network']:.4f}  K3 {k['synthesis']:.4f}  "
-          f"K0+launch gaps {rest:.4f}  | tile env {os.environ.get('RNNOISE_AMD_MFMA_TILE', '-')}")
+          f"K0+launch gaps {rest:.4f}")
     b.close()
