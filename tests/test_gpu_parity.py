@@ -207,6 +207,50 @@ def test_full_size_batch_properties(model, blob_default):
     assert_bits_equal(b.export_state(4095), want["state"][15], "state of the last stream")
 
 
+def fuzz_pcm(n_streams, n_frames, seed):
+    """signal shapes the fixed recipe of rnnoise_amd.synth does not reach: pure and two-tone periodic signals over
+    the whole pitch range (period 30..800 samples, so that remove_doubling's sub-multiples and its minimum-period
+    stop are exercised), period jumps, clicks, full-scale and near-silent levels, DC offsets, white and no noise"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = n_frames * 480
+    t = np.arange(n)
+    out = np.zeros((n_frames, n_streams, 480), np.float32)
+    for s_ in range(n_streams):
+        period = rng.uniform(30, 800)
+        if rng.random() < 0.3:  # period jump mid-way (continuity logic: prev_period / prev_gain)
+            period = np.where(t < rng.integers(480, n), period, period * rng.choice([0.5, 2.0, 1.5, 0.98]))
+        ph = 2 * np.pi * np.cumsum(1.0 / np.broadcast_to(period, (n,)))
+        nh = int(rng.integers(1, 12))
+        x = sum(rng.uniform(0.2, 1.0) * np.sin(k * ph + rng.uniform(0, 6.28)) for k in range(1, nh + 1))
+        if rng.random() < 0.3:  # second, unrelated tone
+            x = x + rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * t / rng.uniform(30, 800))
+        x = x / max(np.abs(x).max(), 1e-9)
+        amp = 10 ** rng.uniform(0.3, 4.5)  # 2 .. 31623: below the silence threshold up to clipping
+        x = amp * x + rng.choice([0.0, 0.0, 30.0, 3000.0]) * rng.standard_normal(n) + rng.choice([0.0, 0.0, 500.0, -4000.0])
+        if rng.random() < 0.2:
+            x[rng.integers(0, n, 5)] += rng.choice([-30000.0, 30000.0], 5)  # clicks
+        out[:, s_, :] = np.clip(np.rint(x), -32768, 32767).astype(np.float32).reshape(n_frames, 480)
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_signal_shapes_bit_exact(model, blob_default, seed):
+    N, T = 160, 30
+    pcm = fuzz_pcm(N, T, seed)
+    b = capi.Batch(model, N)
+    got = gpu_run(b, pcm)
+    want = oracle_run(blob_default, pcm)
+    assert len(np.unique(want["pitch"])) > 40, "the fuzz set must spread over the pitch range"
+    assert_bits_equal(got["gains"], want["gains"], "gains")
+    assert_bits_equal(got["vad"], want["vad"], "vad")
+    assert_bits_equal(got["out"], want["out"], "pcm")
+    f, sil, pit = b.debug_last()
+    assert np.array_equal(pit, want["pitch"][-1]) and np.array_equal(sil, want["silence"][-1])
+    assert_bits_equal(f, want["features"][-1], "features of the last frame")
+    for s_ in range(0, N, 7):
+        assert_bits_equal(b.export_state(s_), want["state"][s_], f"state of stream {s_}")
+
+
 def test_16384_stream_batch_properties(model, blob_default):
     """16384 streams (4 network tiles per CU): replicated streams stay identical, a sample matches the
     oracle bit for bit, and one stream starts silent (network skipped, state frozen) while its tile
