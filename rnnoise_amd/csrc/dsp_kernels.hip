@@ -9,9 +9,12 @@
 // citations (paths relative to /root/reference) are repeated at each stage.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rn_dev.h"
 
 #define WAVE 64
+#define RN_K1_LEAN_MIN_STREAMS 3072  // see rn_analysis_lean_kernel
+#define RN_K1_LEAN_MAX_STREAMS 12288
 
 struct cpx { float r, i; };
 
@@ -956,6 +959,15 @@ extern "C" __global__ void __launch_bounds__(WAVE)
 rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
   analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
 }
+// The same kernel held to 80 VGPRs (a few registers spilled, ~1 % slower by itself).  While a 16-stream tile of
+// the network kernel is resident on a CU (2 waves x 120 VGPRs per SIMD), only 272 VGPRs per SIMD are left: two
+// waves of the 104-register build, three of this one -- 12 analysis waves beside the tile instead of 8, which is
+// also what the LDS allows.  Measured (same box): +7.7 % at 4096 streams, +2.3 % at 8192, 0 at 6144, -2.5 % at
+// <= 2048 (too few waves for it to matter), -0.7 % at 65,536 (no overlap left) => used from 3072 to 12287 streams.
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
+rn_analysis_lean_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
+  analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
+}
 
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
 extern "C" __global__ void __launch_bounds__(WAVE)
@@ -1135,7 +1147,12 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slo
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st) {
-  hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
+  static const int force = [] { const char *e = getenv("RNNOISE_AMD_K1_LEAN"); return e ? atoi(e) : -1; }();  // 0 / 1: A/B runs
+  const bool lean = force >= 0 ? force != 0 : (g->n_streams >= RN_K1_LEAN_MIN_STREAMS && g->n_streams < RN_K1_LEAN_MAX_STREAMS);
+  if (lean)
+    hipLaunchKernelGGL(rn_analysis_lean_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
+  else
+    hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
