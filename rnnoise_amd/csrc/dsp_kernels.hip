@@ -179,16 +179,6 @@ __device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float 
   __syncthreads();
 }
 
-// src/denoise.c:140-154 evaluated per bin; bins >= 400 are 0 for every caller
-__device__ __forceinline__ float interp_gain_bin(const float *bandE, int bin, const RnTablesDev &tb) {
-  if (bin >= 400) return 0.f;
-  const int i = tb.band_of_bin[bin];
-  if (i == 0) return bandE[0];
-  if (i == RN_NB_BANDS) return bandE[RN_NB_BANDS - 1];
-  const float frac = tb.band_frac[bin];
-  return (1 - frac) * bandE[i - 1] + frac * bandE[i];
-}
-
 // src/denoise.c:160-170, lane i < 32 produces out[i]; c[j] = rnn_dct_table[j*32 + i], fetched by the
 // caller well before use (the 32 loads are independent of the sum chain)
 __device__ __forceinline__ float dct_lane(const float *in, const float *c, const RnTablesDev &tb) {
@@ -196,12 +186,6 @@ __device__ __forceinline__ float dct_lane(const float *in, const float *c, const
 #pragma unroll
   for (int j = 0; j < RN_NB_BANDS; j++) sum += in[j] * c[j];
   return (float)(sum * tb.dct_scale);
-}
-
-__device__ __forceinline__ float chain_dot(const float *x, const float *y, int n) {  // src/pitch.h:132-142
-  float s = 0;
-  for (int i = 0; i < n; i++) s = s + x[i] * y[i];
-  return s;
 }
 
 __device__ __forceinline__ float lane_bcast(float v, int l) {  // l must be wave-uniform
