@@ -77,10 +77,13 @@ def synth_pcm_torch(torch, n_streams: int, n_frames: int, device, seed_base: int
 
 def measured_traffic(kernel: str, n_streams: int):
     """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction), scaled to this batch size."""
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction; measured at 4096 and 65,536 streams),
+    per-frame figure of the nearer measurement scaled to this batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            k = json.load(f)["kernels"]
+            sets = json.load(f)["by_streams"]
+        k = sets[min(sets, key=lambda n: abs(int(n) - n_streams))]
+        kernel = kernel.replace("_lean", "")  # the 80-VGPR build is listed under the plain name
         if kernel == "rn_analysis_kernel":
             per = k["rn_analysis_kernel"]["hbm_bytes_per_frame"] + k["rn_hp_kernel"]["hbm_bytes_per_frame"]
         else:
@@ -215,6 +218,8 @@ def main():
         dom = max(("analysis", "network", "synthesis"), key=lambda k: kms[k])
         ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         kname = f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel"
+        if dom == "analysis" and 3072 <= N < 12288 and os.environ.get("RNNOISE_AMD_K1_LEAN", "1") != "0":
+            kname = "rn_analysis_lean_kernel"  # same code held to 80 VGPRs (dsp_kernels.hip: RN_K1_LEAN_MIN/MAX_STREAMS)
         line = {
             "metric": "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": a.gpus, "steps": K, "warmup": Wm,

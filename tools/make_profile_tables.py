@@ -51,12 +51,13 @@ for n_streams in (4096, 65536):
               f"{100 * g('SQ_ACTIVE_INST_VALU') / (g('SQ_WAVE_CYCLES') or 1):>11.1f}{100 * g('SQ_WAIT_ANY') / (g('SQ_WAVE_CYCLES') or 1):>7.1f}"
               f"{g('TCP_TOTAL_CACHE_ACCESSES_sum'):>14.0f}{100 * g('TCC_HIT_sum') / ((g('TCC_HIT_sum') + g('TCC_MISS_sum')) or 1):>8.1f}"
               f"{g('FETCH_SIZE'):>11.0f}{g('WRITE_SIZE'):>11.0f}{hbm:>12.0f}\n")
-        if n_streams == 4096:
-            traffic[r["kernel"]] = {"hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"),
-                                    "write_kib_per_launch": g("WRITE_SIZE"), "streams": n_streams}
+        traffic.setdefault(str(n_streams), {})[r["kernel"].replace("_lean", "")] = {
+            "hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"),
+            "write_kib_per_launch": g("WRITE_SIZE"), "kernel": r["kernel"]}
     open(os.path.join(dst, f"{pre}_pmc_{n_streams}.txt"), "w").write(hdr + t)
-json.dump({"source": f"profiles/{pre}_pmc_4096.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read "
-                     "correction), 4096 streams", "kernels": traffic},
+json.dump({"source": f"profiles/{pre}_pmc_4096.txt, {pre}_pmc_65536.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                     "gfx950 x2 read correction); bench.py uses the set measured nearest to its batch size",
+           "by_streams": traffic},
           open(os.path.join(dst, "r1_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{pre}_pmc_4096.txt")).read())
 print(open(os.path.join(dst, f"{pre}_pmc_65536.txt")).read())
