@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import json
 import lzma
+import math
 import os
 import subprocess
 import sys
@@ -82,7 +83,7 @@ def measured_traffic(kernel: str, n_streams: int):
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
             sets = json.load(f)["by_streams"]
-        k = sets[min(sets, key=lambda n: abs(int(n) - n_streams))]
+        k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]  # nearest in octaves
         kernel = kernel.replace("_lean", "")  # the 80-VGPR build is listed under the plain name
         if kernel == "rn_analysis_kernel":
             per = k["rn_analysis_kernel"]["hbm_bytes_per_frame"] + k["rn_hp_kernel"]["hbm_bytes_per_frame"]
