@@ -1130,13 +1130,14 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slo
   hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot, 1);
   return hipGetLastError();
 }
-extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st) {
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st,
+                                         hipEvent_t e0, hipEvent_t e1) {
   static const int force = [] { const char *e = getenv("RNNOISE_AMD_K1_LEAN"); return e ? atoi(e) : -1; }();  // 0 / 1: A/B runs
   const bool lean = force >= 0 ? force != 0 : (g->n_streams >= RN_K1_LEAN_MIN_STREAMS && g->n_streams < RN_K1_LEAN_MAX_STREAMS);
   if (lean)
-    hipLaunchKernelGGL(rn_analysis_lean_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
+    RN_LAUNCH(rn_analysis_lean_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, e0, e1, *g, *tb, slot, parity);
   else
-    hipLaunchKernelGGL(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot, parity);
+    RN_LAUNCH(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, e0, e1, *g, *tb, slot, parity);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
@@ -1147,7 +1148,7 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int cur, int prev,
-                                          hipStream_t st) {
-  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, out, cur, prev);
+                                          hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, out, cur, prev);
   return hipGetLastError();
 }

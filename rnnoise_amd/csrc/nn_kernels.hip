@@ -159,8 +159,8 @@ rn_nn_vector_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 }
 
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb,
-                                          hipStream_t st) {
-  hipLaunchKernelGGL(rn_nn_vector_kernel, dim3(g->n_streams), dim3(NN_THREADS), 0, st, *g, *m, *tb);
+                                          hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  RN_LAUNCH(rn_nn_vector_kernel, dim3(g->n_streams), dim3(NN_THREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
 

@@ -312,9 +312,10 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   CLK_TAP(6);  // dense_out / vad (wave 0's view)
 }
 
-extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st) {
+extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
+                                        hipEvent_t e0, hipEvent_t e1) {
   if (!m->conv2.wmf || !g->nn_act) return hipErrorNotSupported;
-  hipLaunchKernelGGL(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, *g, *m, *tb);
+  RN_LAUNCH(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
 extern "C" int rn_nn_mfma_available(void) { return 1; }

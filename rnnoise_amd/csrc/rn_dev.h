@@ -97,3 +97,14 @@ struct RnTrainArgs {
   const int *noise_free;   // [N] noise_gain==0 && fgnoise_gain==0 (dump_features.c:477)
   float *rec;              // [N][98] out: features[65] | gain targets[32] | vad
 };
+
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+// Launch with an optional (start, stop) event pair: the pair is time-stamped by the dispatch packet itself
+// (hipExtLaunchKernel), so timing a kernel adds no packets to the queue and no fence around it.
+#define RN_LAUNCH(kernel, grid, block, shmem, st, e0, e1, ...)                                          \
+  do {                                                                                                  \
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, e0, e1, 0, __VA_ARGS__);              \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                \
+  } while (0)
+#endif

@@ -19,12 +19,15 @@
 #include "rn_dev.h"
 
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t);
-extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t);
-extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t);
+extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t, hipEvent_t, hipEvent_t);
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t, hipEvent_t,
+                                          hipEvent_t);
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *, const RnTablesDev *, const float *, int, int,
                                                const RnTrainArgs *, hipStream_t);
-extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
-extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t);
+extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
+                                          hipEvent_t);
+extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
+                                        hipEvent_t);
 extern "C" int rn_nn_mfma_available(void);
 
 // batches below this size run K1 on its own stream as well (3-stream schedule, see rnnoise_batch_process_device)
@@ -497,27 +500,27 @@ int batch_flush_timing(RNNoiseBatch *b) {
   return 0;
 }
 
-struct ScopedEvent {
+// A (start, stop) event pair for one kernel launch while timing is enabled; the launch helper hands it to the
+// dispatch packet (hipExtLaunchKernel), the pair is read back in rnnoise_batch_kernel_ms.
+struct TimedLaunch {
   RNNoiseBatch *b;
-  hipStream_t st;
   RNNoiseBatch::Ev ev{};
   bool on;
-  ScopedEvent(RNNoiseBatch *b_, hipStream_t st_, int kind) : b(b_), st(st_), on(b_->timing) {
+  TimedLaunch(RNNoiseBatch *b_, int kind) : b(b_), on(b_->timing) {
     if (!on) return;
     if (!b->pool.empty()) {
       ev = b->pool.back();
       b->pool.pop_back();
     } else {
-      hipEventCreate(&ev.a);
-      hipEventCreate(&ev.b);
+      hipEventCreateWithFlags(&ev.a, hipEventDisableSystemFence);  // timing only: no cache writeback / invalidation
+      hipEventCreateWithFlags(&ev.b, hipEventDisableSystemFence);
     }
     ev.kind = kind;
-    hipEventRecord(ev.a, st);
   }
-  ~ScopedEvent() {
-    if (!on) return;
-    hipEventRecord(ev.b, st);
-    b->pending.push_back(ev);
+  hipEvent_t start() const { return on ? ev.a : nullptr; }
+  hipEvent_t stop() const { return on ? ev.b : nullptr; }
+  ~TimedLaunch() {
+    if (on) b->pending.push_back(ev);
   }
 };
 
@@ -638,11 +641,14 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   if (pipelined && !b->side) {
     HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming));
+    // ordering between streams of ONE device: no system-scope fence (it writes back and invalidates the caches at
+    // every record, which the next kernels then pay for)
+    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+    HIP_OK(hipEventCreateWithFlags(&b->ev_begin, evf));
     for (int k = 0; k < 8; k++) {
-      HIP_OK(hipEventCreateWithFlags(&b->ev_hp[k], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&b->ev_k1[k], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&b->ev_hp[k], evf));
+      HIP_OK(hipEventCreateWithFlags(&b->ev_k1[k], evf));
+      HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], evf));
     }
   }
   hipStream_t sb = side_k1 ? b->side : st, sc = pipelined ? b->side_hp : st;
@@ -674,8 +680,9 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       if (side_k1 && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 7], 0));
     }
     {
-      ScopedEvent ev(b, sb, 0);
-      HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb));
+      TimedLaunch t(b, 0);
+      HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb, t.start(),
+                                t.stop()));
     }
     if (pipelined) HIP_OK(hipEventRecord(b->ev_k1[f & 7], sb));
     return 0;
@@ -696,13 +703,13 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 7], 0));
     }
     {
-      ScopedEvent ev(b, st, 1);
-      if (b->nn_path == 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st));
-      else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st));
+      TimedLaunch t(b, 1);
+      if (b->nn_path == 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+      else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
     }
     {
-      ScopedEvent ev(b, st, 2);
-      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st));
+      TimedLaunch t(b, 2);
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st, t.start(), t.stop()));
     }
     if (side_k1) HIP_OK(hipEventRecord(b->ev_k3[f & 7], st));
     b->launches += b->timing ? 1 : 0;
