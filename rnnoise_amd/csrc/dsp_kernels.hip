@@ -344,11 +344,19 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
   const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
   float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
-  float4 nxt = x[0];
-  for (int i = 0; i < RN_FRAME_SIZE / 4; i++) {
-    const float4 v = nxt;
-    if (i + 1 < RN_FRAME_SIZE / 4) nxt = x[i + 1];
-    float4 o;
+  // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
+  // filtered: with one wave per SIMD nothing else hides the HBM round trip
+  constexpr int BLK = 8;  // float4 per block
+  float4 cur[BLK], nxt[BLK];
+#pragma unroll
+  for (int j = 0; j < BLK; j++) nxt[j] = x[j];
+  for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
+#pragma unroll
+    for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+    if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) nxt[j] = x[(blk + 1) * BLK + j];
+    }
 #define HP_STEP(xi, yo)                                              \
     {                                                                \
       const float yi = (xi) + m0;                                    \
@@ -357,13 +365,18 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
       m1 = (float)fma(na1, yd, xd);                                  \
       (yo) = yi;                                                     \
     }
-    if (apply_hp) {
-      HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
-    } else {
-      o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      const float4 v = cur[j];
+      float4 o;
+      if (apply_hp) {
+        HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+      } else {
+        o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
+      }
+      y[blk * BLK + j] = o;
     }
 #undef HP_STEP
-    y[i] = o;
   }
   if (apply_hp) {
     g.mem_hp[2 * s] = m0;
@@ -379,41 +392,51 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
   {
     const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
     const int ring0 = RN_RING0(slot);
-    auto chunk = [&](int c) {  // pitch_buf[4c .. 4c+3]; ring0 and the ring size are multiples of 4
-      int p = ring0 + 4 * c;
+    // pitch_buf in blocks of 32 floats (8 float4); ring0 and the ring size are multiples of 32, so a block never
+    // straddles the wrap; the next block is requested before this one is consumed
+    auto block = [&](int b, float4 (&dst)[BLK]) {
+      int p = ring0 + 32 * b;
       p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
-      return *reinterpret_cast<const float4 *>(ring + p);
+      const float4 *src = reinterpret_cast<const float4 *>(ring + p);
+#pragma unroll
+      for (int j = 0; j < BLK; j++) dst[j] = src[j];
     };
     float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
     float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
     float prev = 0;                          // pitch_buf[4c-1]
-    float4 q = chunk(0);
-    for (int c = 0; c < RN_PITCH_BUF_SIZE / 4; c++) {
-      const float4 v = q;
-      if (c + 1 < RN_PITCH_BUF_SIZE / 4) q = chunk(c + 1);
-      float xl[2];
-      xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
-      xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
-      prev = v.w;
+    block(0, nxt);
+    for (int b = 0; b < RN_PITCH_BUF_SIZE / 32; b++) {
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int t = 2 * c + h;
-        const float x0 = xl[h];
-        if (t < 860) {
-          ac[0] = ac[0] + x0 * x0;
-          ac[1] = ac[1] + w1 * x0;
-          ac[2] = ac[2] + w2 * x0;
-          ac[3] = ac[3] + w3 * x0;
-          ac[4] = ac[4] + w4 * x0;
-        } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
-          const int e = t - 860;
-          d[0] = d[0] + x0 * x0;
-          if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
-          if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
-          if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
-          ac[4] = ac[4] + w4 * x0;
+      for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+      if (b + 1 < RN_PITCH_BUF_SIZE / 32) block(b + 1, nxt);
+#pragma unroll
+      for (int j = 0; j < BLK; j++) {
+        const int c = b * BLK + j;
+        const float4 v = cur[j];
+        float xl[2];
+        xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
+        xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
+        prev = v.w;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int t = 2 * c + h;
+          const float x0 = xl[h];
+          if (t < 860) {
+            ac[0] = ac[0] + x0 * x0;
+            ac[1] = ac[1] + w1 * x0;
+            ac[2] = ac[2] + w2 * x0;
+            ac[3] = ac[3] + w3 * x0;
+            ac[4] = ac[4] + w4 * x0;
+          } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
+            const int e = t - 860;
+            d[0] = d[0] + x0 * x0;
+            if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
+            if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
+            if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
+            ac[4] = ac[4] + w4 * x0;
+          }
+          w4 = w3; w3 = w2; w2 = w1; w1 = x0;
         }
-        w4 = w3; w3 = w2; w2 = w1; w1 = x0;
       }
     }
 #pragma unroll
