@@ -30,8 +30,6 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, 
                                         hipEvent_t);
 extern "C" int rn_nn_mfma_available(void);
 
-// batches below this size run K1 on its own stream as well (3-stream schedule, see rnnoise_batch_process_device)
-#define RN_PIPE3_MAX_STREAMS 32768
 
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
@@ -632,12 +630,12 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   //   * the spectra rotate through 3 slots and the per-step scratch (features, silence, pitch) is
   //     double-buffered, so analysis(f) only has to wait for synthesis(f-2);
   //   * every other piece of state is touched by one kernel only, in frame order on its own stream.
-  const bool pipelined = n_frames > 1;
-  // Once the batch fills every CU several times over, running K1 beside K2/K3 only makes them thrash each
-  // other (measured: 65,536 streams are 8 % faster with K1 back on the caller's stream); the latency-bound
-  // K0 stays on its side stream at every size.  RNNOISE_AMD_PIPE = 1 / 2 forces the 2- / 3-stream schedule.
+  // RNNOISE_AMD_PIPE (A/B runs only): 9 = no side streams, 1 = K0 on a side stream, 2 = K0 and K1 on side streams.
+  // Measured after the fence-free events: the 3-stream schedule is the best or within noise of the best from 1 K to
+  // 64 K streams (65,536: 20.2 M frames/s vs 20.0 M on one stream, 19.6 M with only K0 aside), so it is the only default.
   static const int pipe_force = [] { const char *e = getenv("RNNOISE_AMD_PIPE"); return e ? atoi(e) : 0; }();
-  const bool side_k1 = pipelined && (pipe_force ? pipe_force >= 2 : b->n < RN_PIPE3_MAX_STREAMS);
+  const bool pipelined = n_frames > 1 && pipe_force != 9;
+  const bool side_k1 = pipelined && pipe_force != 1;
   if (pipelined && !b->side) {
     HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));

@@ -435,15 +435,16 @@ def test_pipeline_chunking_is_invisible(model, blob_default):
             assert_bits_equal(b.export_state(i), want["state"][i], f"state {i}")
 
 
-def test_two_stream_schedule_forced():
-    """large batches keep K1 on the caller's stream (2-stream schedule); RNNOISE_AMD_PIPE=1 forces that schedule
-    (read once per process) for the chunking / in-place / MFMA parity cases at test sizes"""
+@pytest.mark.parametrize("mode", ["1", "9"])
+def test_other_stream_schedules_forced(mode):
+    """RNNOISE_AMD_PIPE (read once per process) selects the A/B schedules -- 1: only K0 on a side stream, 9: no side
+    streams; the chunking / in-place / MFMA parity cases must not notice"""
     import os
     import subprocess
     import sys
     if os.environ.get("RNNOISE_AMD_PIPE"):
         pytest.skip("already inside a forced run")
-    env = dict(os.environ, RNNOISE_AMD_PIPE="1")
+    env = dict(os.environ, RNNOISE_AMD_PIPE=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
                         "test_pipeline_chunking or test_device_call_in_place or test_mfma_path_bit_exact"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
