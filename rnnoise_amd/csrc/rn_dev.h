@@ -100,11 +100,11 @@ struct RnTrainArgs {
 
 #ifdef __HIPCC__
 #include <hip/hip_ext.h>
-// Launch with an optional (start, stop) event pair: the pair is time-stamped by the dispatch packet itself
-// (hipExtLaunchKernel), so timing a kernel adds no packets to the queue and no fence around it.
+// Launch with optional start / stop events: they are bound to the dispatch packet itself (hipExtLaunchKernel), so
+// timing a kernel or publishing its completion to another stream adds no packets to the queue.
 #define RN_LAUNCH(kernel, grid, block, shmem, st, e0, e1, ...)                                          \
   do {                                                                                                  \
-    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, e0, e1, 0, __VA_ARGS__);              \
+    if ((e0) || (e1)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, e0, e1, 0, __VA_ARGS__);              \
     else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                \
   } while (0)
 #endif

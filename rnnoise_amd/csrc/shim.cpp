@@ -18,7 +18,7 @@
 #include "rcp_lut_x86.h"
 #include "rn_dev.h"
 
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t, hipEvent_t);
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t, hipEvent_t,
                                           hipEvent_t);
@@ -378,7 +378,10 @@ struct RNNoiseBatch {
   // side stream + events: in multi-frame calls the (latency-bound, 1 lane per stream) high-pass of frame
   // f+1 runs beside analysis/network/synthesis of frame f
   hipStream_t side = nullptr, side_hp = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_hp[8] = {}, ev_k1[8] = {}, ev_k3[8] = {};
+  // ordering events of the pipelined schedule: own_* are the batch's persistent events, cur_* the handle that marks the
+  // completion of hp / analysis / synthesis of frame f & 7 (an own_* event, or the stop event of a timed launch)
+  hipEvent_t ev_begin = nullptr, own_hp[8] = {}, own_k1[8] = {}, own_k3[8] = {};
+  hipEvent_t cur_hp[8] = {}, cur_k1[8] = {}, cur_k3[8] = {};
   void *arena = nullptr;
   size_t arena_bytes = 0;
   RnGroupDev g{};
@@ -591,7 +594,7 @@ extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
     hipStreamDestroy(b->side);
     hipStreamDestroy(b->side_hp);
     hipEventDestroy(b->ev_begin);
-    for (int k = 0; k < 8; k++) { hipEventDestroy(b->ev_hp[k]); hipEventDestroy(b->ev_k1[k]); hipEventDestroy(b->ev_k3[k]); }
+    for (int k = 0; k < 8; k++) { hipEventDestroy(b->own_hp[k]); hipEventDestroy(b->own_k1[k]); hipEventDestroy(b->own_k3[k]); }
   }
   delete b;
 }
@@ -644,9 +647,9 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
     HIP_OK(hipEventCreateWithFlags(&b->ev_begin, evf));
     for (int k = 0; k < 8; k++) {
-      HIP_OK(hipEventCreateWithFlags(&b->ev_hp[k], evf));
-      HIP_OK(hipEventCreateWithFlags(&b->ev_k1[k], evf));
-      HIP_OK(hipEventCreateWithFlags(&b->ev_k3[k], evf));
+      HIP_OK(hipEventCreateWithFlags(&b->own_hp[k], evf));
+      HIP_OK(hipEventCreateWithFlags(&b->own_k1[k], evf));
+      HIP_OK(hipEventCreateWithFlags(&b->own_k3[k], evf));
     }
   }
   hipStream_t sb = side_k1 ? b->side : st, sc = pipelined ? b->side_hp : st;
@@ -666,23 +669,25 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     return g;
   };
   auto highpass = [&](int f) -> int {  // K0 of frame f on stream sc
-    if (pipelined && f >= 3) HIP_OK(hipStreamWaitEvent(sc, b->ev_k1[(f - 3) & 7], 0));
-    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc));
-    if (pipelined) HIP_OK(hipEventRecord(b->ev_hp[f & 7], sc));
+    // completion events ride in the dispatch packets (stop event of hipExtLaunchKernel): no record packets between
+    // the kernels of a stream
+    if (pipelined && f >= 3) HIP_OK(hipStreamWaitEvent(sc, b->cur_k1[(f - 3) & 7], 0));
+    b->cur_hp[f & 7] = pipelined ? b->own_hp[f & 7] : nullptr;
+    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc, b->cur_hp[f & 7]));
     return 0;
   };
   auto analysis = [&](int f) -> int {  // K1 of frame f on stream sb
     RnGroupDev g = frame_group(f);
     if (pipelined) {
-      HIP_OK(hipStreamWaitEvent(sb, b->ev_hp[f & 7], 0));
-      if (side_k1 && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->ev_k3[(f - 2) & 7], 0));
+      HIP_OK(hipStreamWaitEvent(sb, b->cur_hp[f & 7], 0));
+      if (side_k1 && f >= 2) HIP_OK(hipStreamWaitEvent(sb, b->cur_k3[(f - 2) & 7], 0));
     }
     {
       TimedLaunch t(b, 0);
+      b->cur_k1[f & 7] = t.on ? t.stop() : (pipelined ? b->own_k1[f & 7] : nullptr);
       HIP_OK(rn_launch_analysis(&g, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, (b->parity + f) % RN_SPEC_SLOTS, sb, t.start(),
-                                t.stop()));
+                                b->cur_k1[f & 7]));
     }
-    if (pipelined) HIP_OK(hipEventRecord(b->ev_k1[f & 7], sb));
     return 0;
   };
   if (pipelined) {
@@ -698,7 +703,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     } else {
       if (f + 3 < n_frames && highpass(f + 3)) return -1;
       if (f + 1 < n_frames && analysis(f + 1)) return -1;
-      if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->ev_k1[f & 7], 0));
+      if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->cur_k1[f & 7], 0));
     }
     {
       TimedLaunch t(b, 1);
@@ -707,9 +712,9 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     }
     {
       TimedLaunch t(b, 2);
-      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st, t.start(), t.stop()));
+      b->cur_k3[f & 7] = t.on ? t.stop() : (side_k1 ? b->own_k3[f & 7] : nullptr);
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st, t.start(), b->cur_k3[f & 7]));
     }
-    if (side_k1) HIP_OK(hipEventRecord(b->ev_k3[f & 7], st));
     b->launches += b->timing ? 1 : 0;
   }
   b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;
