@@ -219,7 +219,7 @@ def main():
         dom = max(("analysis", "network", "synthesis"), key=lambda k: kms[k])
         ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         kname = f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel"
-        if dom == "analysis" and 3072 <= N < 12288 and os.environ.get("RNNOISE_AMD_K1_LEAN", "1") != "0":
+        if dom == "analysis" and 3072 <= N < 24576 and os.environ.get("RNNOISE_AMD_K1_LEAN", "1") != "0":
             kname = "rn_analysis_lean_kernel"  # same code held to 80 VGPRs (dsp_kernels.hip: RN_K1_LEAN_MIN/MAX_STREAMS)
         line = {
             "metric": "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline",

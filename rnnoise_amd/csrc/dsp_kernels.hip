@@ -14,7 +14,7 @@
 
 #define WAVE 64
 #define RN_K1_LEAN_MIN_STREAMS 3072  // see rn_analysis_lean_kernel
-#define RN_K1_LEAN_MAX_STREAMS 12288
+#define RN_K1_LEAN_MAX_STREAMS 24576
 
 struct cpx { float r, i; };
 
@@ -969,8 +969,9 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
 // The same kernel held to 80 VGPRs (a few registers spilled, ~1 % slower by itself).  While a 16-stream tile of
 // the network kernel is resident on a CU (2 waves x 120 VGPRs per SIMD), only 272 VGPRs per SIMD are left: two
 // waves of the 104-register build, three of this one -- 12 analysis waves beside the tile instead of 8, which is
-// also what the LDS allows.  Measured (same box): +7.7 % at 4096 streams, +2.3 % at 8192, 0 at 6144, -2.5 % at
-// <= 2048 (too few waves for it to matter), -0.7 % at 65,536 (no overlap left) => used from 3072 to 12287 streams.
+// also what the LDS allows.  Measured (same box): +7.7 % at 4096 streams, +2.3 % at 8192, 0 at 6144, +1.5 % at 16,384,
+// -2.5 % at <= 2048 (too few waves for it to matter), -0.6 % at 32,768 and 65,536 (no overlap left)
+// => used from 3072 to 24575 streams.
 extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 rn_analysis_lean_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
   analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
