@@ -3,15 +3,26 @@
 
 Metric (BASELINE.json): 10 ms frames/s (48 kHz mono) summed over N concurrent streams, and
 the fraction of the HBM roofline.  A "step" is one pass of the hot path over one batch: every
-stream of the batch advances by one 480-sample frame (analysis -> network -> synthesis).
+stream of the batch advances by one 480-sample frame (high-pass -> analysis -> network ->
+synthesis).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--nn vector|mfma]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--model default|little]
+                  [--nn mfma|vector] [--repeats R] [--host-io]
 
-Workload at N=1: BASELINE.json configs[1] -- 4096 concurrent streams on one MI355X, default
-architecture, int8 model -- run on the faster of the two bit-identical network paths (batched
-MFMA; `--nn vector` selects the v_dot4 path configs[1] names, `--streams 65536` is configs[2]).  With --gpus N every rank owns its own S streams (independent
-streams shard trivially, SURVEY 8e: "weak" scaling, no data-path collective); the only
-collectives are the barrier and the max/sum over ranks of (elapsed, frames).
+Workload at N=1: BASELINE.json configs[2] -- 65,536 concurrent streams on one MI355X (the largest
+single-GPU configuration), default architecture, int8 model, network recast as batched MFMA
+GEMMs.  `--streams 4096 [--nn vector]` is configs[1], `--model little --streams 32768` is
+configs[3].  With --gpus N every rank owns its own S streams (N x 65,536 = configs[4] at N=8:
+independent streams shard trivially, SURVEY 8e: "weak" scaling, no data-path collective); the only
+collectives are the barriers and the max-over-ranks of the elapsed times.
+
+`python bench.py --gpus N` may be started directly (it re-executes itself under
+torch.distributed.run, one rank per GPU) or under a launcher that already set RANK / WORLD_SIZE.
+
+Timing: W untimed warm-up steps, then R repetitions (default 25) of EXACTLY K steps, each
+bracketed by barrier + synchronize on both sides; every repetition's time is the MAX over
+ranks; `value` is the median repetition (min / max are reported beside it) and
+`ms_per_step x steps` is that repetition.
 
 The model is the synthetic default-architecture blob produced by the reference's own
 exporter (the trained weights are a separate download upstream; tests/golden/make_golden.py).
@@ -26,6 +37,8 @@ import json
 import lzma
 import math
 import os
+import socket
+import statistics
 import subprocess
 import sys
 import tempfile
@@ -34,20 +47,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9    # max shader clock (same guide)
+N_SIMD = 256 * 4    # CUs x SIMDs
 FRAME = 480
+METRIC = "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline"
 
-# algorithmic HBM bytes per stream-frame of each kernel (DESIGN.md "kernels"); W is added to
-# the network kernel at run time from the model
-# analysis = K0 (in 1920 r, ring slot 1920 w, hp state 16) + K1 (ring: 6912 downsample + 2 x 3840 windows r,
-# X re-read 3200 r; X,P 7696 + E 384 + features 260 + flags 12 w)
-ANALYSIS_BYTES = (1920 + 1920 + 16) + (6912 + 3840 + 3840 + 3200) + (7696 + 384 + 260 + 12)
-SYNTHESIS_BYTES = 3848 + 3848 + 384 + 128 + 128 + 256 + 1920 + 1920 + 1920
-NETWORK_STATE_BYTES = 260 + 2 * (520 + 1024 + 4608) + 128 + 4
+# Algorithmic HBM bytes per stream-frame of each kernel; W is added to the network
+# kernel per LAUNCH from the model: the weights are read from HBM at most once per launch.
+#   K0: input 1920 r + ring slot 1920 w + hp state 8 r + 8 w + pitch_buf 6912 r (autocorrelation) + 5 taps 20 w
+#   K1: ring 6912 (downsample) + 2 x 3840 (windows) r, X re-read 3200 r, taps 20 r; X,P 7696 + E 384 + features 260 + flags 12 w
+#   K2: features 260 r, conv/GRU state 2 x (520 + 1024 + 4608), gains 128 + vad 4 w
+#   K3: X,P 7696 + E 2 x 384 + gains 128 + lastg 2 x 128 + synth_mem 2 x 1920 r/w + out 1920 w
+ALG_BYTES = {
+    "highpass": 1920 + 1920 + 16 + 6912 + 20,
+    "analysis": (6912 + 3840 + 3840 + 3200 + 20) + (7696 + 384 + 260 + 12),
+    "network": 260 + 2 * (520 + 1024 + 4608) + 128 + 4,
+    "synthesis": 3848 + 3848 + 384 + 128 + 128 + 256 + 1920 + 1920 + 1920,
+}
+KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "network": "rn_nn_mfma_kernel",
+             "synthesis": "rn_synthesis_kernel"}
 
 
-def load_blob() -> bytes:
-    with open(os.path.join(ROOT, "tests", "golden", "default.blob.xz"), "rb") as f:
+def waves_per_launch(kind: str, n_streams: int) -> int:
+    return {"highpass": -(-n_streams // 64), "analysis": n_streams, "network": -(-n_streams // 16) * 8,
+            "synthesis": n_streams}[kind]
+
+
+def load_blob(name: str = "default") -> bytes:
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.blob.xz"), "rb") as f:
         return lzma.decompress(f.read())
 
 
@@ -76,45 +104,65 @@ def synth_pcm_torch(torch, n_streams: int, n_frames: int, device, seed_base: int
     return out
 
 
-def measured_traffic(kernel: str, n_streams: int):
-    """HBM bytes per launch from the committed PMC passes (profiles/r1_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction; measured at 4096 and 65,536 streams),
-    per-frame figure of the nearer measurement scaled to this batch size."""
+def pmc_record(kernel: str, n_streams: int):
+    """Per-kernel counters from the committed PMC passes (profiles/pmc_by_streams.json, written by
+    tools/make_profile_tables.py from rocprofv3 --pmc runs: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU in separate passes,
+    gfx950 x2 read correction): the set measured nearest (in octaves) to this batch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_by_streams.json")) as f:
             sets = json.load(f)["by_streams"]
-        k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]  # nearest in octaves
-        kernel = kernel.replace("_lean", "")  # the 80-VGPR build is listed under the plain name
-        if kernel == "rn_analysis_kernel":
-            per = k["rn_analysis_kernel"]["hbm_bytes_per_frame"] + k["rn_hp_kernel"]["hbm_bytes_per_frame"]
-        else:
-            per = k[kernel]["hbm_bytes_per_frame"]
-        return int(per * n_streams)
+        k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]
+        return k.get(kernel) or k.get(kernel.replace("_lean", ""))
     except Exception:
         return None
 
 
+def cgroup_cpu_quota():
+    """CPUs the cgroup allows (cpu.max / cfs quota), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(math.ceil(int(q) / int(p))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(math.ceil(q / p)))
+    except Exception:
+        pass
+    return None
+
+
+def usable_cpus() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cgroup_cpu_quota()
+    return max(1, min(n, q) if q else n)
+
+
 def cpu_baseline(blob: bytes):
-    """Reference (or port) on the host cores, bounded to ~12 s; see oracle/cpu_bench.c."""
+    """The reference itself (oracle/_ref, kind "reference") or our restatement (kind "port") on the host cores:
+    a 1-thread leg (~5 s) and an all-usable-cores leg (~12 s); see oracle/cpu_bench.c."""
     import numpy as np
     from rnnoise_amd import synth
     ref = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
     port = os.path.join(ROOT, "oracle", "cpu_bench_port")
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench_port"], stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)  # always rebuilt from the source under review (a no-op when up to date)
     with tempfile.TemporaryDirectory() as td:
         bp, pp = os.path.join(td, "m.blob"), os.path.join(td, "pcm.s16")
         open(bp, "wb").write(blob)
         np.concatenate([synth.stream_pcm(s, 200) for s in range(8)]).tofile(pp)
         for exe, kind in ((ref, "reference"), (port, "port")):
             if not os.path.exists(exe):
-                if kind == "port":
-                    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench_port"],
-                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                if not os.path.exists(exe):
-                    continue
+                continue
             try:
-                r = subprocess.run([exe, bp, pp, str(cores), "12"], capture_output=True, text=True, timeout=120)
-                j = json.loads(r.stdout.strip().splitlines()[-1])
+                legs = []
+                for threads, secs in ((1, 5), (cores, 12)):
+                    r = subprocess.run([exe, bp, pp, str(threads), str(secs)], capture_output=True, text=True, timeout=120)
+                    legs.append(json.loads(r.stdout.strip().splitlines()[-1]))
             except Exception:
                 continue
             cpu = "unknown"
@@ -125,129 +173,236 @@ def cpu_baseline(blob: bytes):
                         break
             except OSError:
                 pass
-            return {"value": round(j["frames_per_s"], 1), "unit": "frames/s", "cores": j["threads"], "kind": kind,
-                    "sample": f"{j['frames']} frames in {j['seconds']:.1f} s: {cores} threads x 1 stream each, "
-                              f"200-frame synthetic PCM looped in memory, same blob; host CPU {cpu}"}
+            one, many = legs
+            return {"value": round(many["frames_per_s"], 1), "unit": "frames/s", "cores": many["threads"], "kind": kind,
+                    "frames_per_s_per_core": round(many["frames_per_s"] / many["threads"], 1),
+                    "one_thread_frames_per_s": round(one["frames_per_s"], 1),
+                    "sample": f"{many['frames']} frames in {many['seconds']:.1f} s on {many['threads']} threads (one stream "
+                              f"each; threads = min(sched_getaffinity {len(os.sched_getaffinity(0))}, cgroup quota "
+                              f"{cgroup_cpu_quota()}), os.cpu_count {os.cpu_count()}) + {one['frames']} frames in "
+                              f"{one['seconds']:.1f} s on 1 thread; 200-frame synthetic PCM looped in memory, same blob; "
+                              f"host CPU {cpu}"}
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=4096, help="concurrent streams PER GPU (configs[1]: 4096)")
-    ap.add_argument("--nn", choices=["vector", "mfma"], default=os.environ.get("RNNOISE_AMD_NN", "mfma"),
-                    help="network path: batched MFMA (default) or the v_dot4 vector path; identical bits")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+class StubBatch:
+    """Launcher self-test only (--stub, CPU + gloo; tests/test_bench_launcher_cpu.py): stands in for capi.Batch so that
+    the rank / shard / aggregate / rank-0-JSON logic of THIS file can run where no GPU exists.  It computes nothing; the
+    line it yields is marked "stub": true and carries a metric name no report can mistake for a measurement."""
 
+    def __init__(self, n):
+        self.n = n
+
+    def set_nn_path(self, p):
+        return 1
+
+    def process_device(self, *a):
+        time.sleep(2e-4)
+
+    def enable_timing(self, on=True):
+        pass
+
+    def kernel_ms(self):
+        return dict(analysis=0.3, network=0.2, synthesis=0.1, highpass=0.05, launches=1)
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(a) -> int:
+    """`python bench.py --gpus N` started directly: become N ranks of torch.distributed.run on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    return subprocess.call(cmd, env=env)
+
+
+def workload_name(a, n_streams: int) -> str:
+    cfg = {("default", 65536): "configs[2]", ("default", 4096): "configs[1]", ("little", 32768): "configs[3]"}.get(
+        (a.model, n_streams), "custom size")
+    if a.gpus == 8 and a.model == "default" and n_streams == 65536:
+        cfg = "configs[4] (8 x configs[2])"
+    dens = "density 1/3" if a.model == "default" else "sparser blob (rnnoise_data_little stand-in)"
+    return (f"BASELINE {cfg}: {n_streams} concurrent streams per GPU, default architecture (conv 65x3->128->384, "
+            f"3xGRU(384) block-sparse int8, {dens}), synthetic exporter-made model, network path = {a.nn}"
+            + (", host-fed (pinned, double-buffered PCIe)" if a.host_io else ""))
+
+
+def bench_rank(a) -> dict | None:
+    """One rank of the benchmark (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Returns the JSON line's dict
+    on rank 0, None elsewhere."""
     import torch
-    from rnnoise_amd import capi
+    from rnnoise_amd.dist import aggregate_times, shard_streams
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        a.gpus = world
-    if not torch.cuda.is_available():
+    a.gpus = world
+    stub = a.stub
+    if not stub and not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    blob = load_blob()
-    model = capi.Model(blob)
-    W = model.weight_bytes
-    N, K, Wm = a.streams, a.steps, a.warmup
-    batch = capi.Batch(model, N, device=local_rank)
-    batch.set_nn_path(1 if a.nn == "mfma" else 0)
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
-    # inputs resident in HBM; cycle through at most `cap` distinct frames if K+W is large
-    cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))
-    d_in = synth_pcm_torch(torch, N, cap, dev, seed_base=rank * N)
-    d_out = torch.empty_like(d_in)
-    d_vad = torch.empty((cap, N), device=dev)
-    d_gains = torch.empty((cap, N, 32), device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    def barrier():
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
+
+    # weak scaling: `streams` per GPU; this rank's global stream ids seed its signals
+    N, K, Wm, R = a.streams, a.steps, a.warmup, a.repeats
+    mine = shard_streams(N * world, world, rank)
+    assert len(mine) == N
+    blob = load_blob(a.model)
+    if stub:
+        W, batch, model = 1521668, StubBatch(N), None
+        cap, d_in = 8, None
+    else:
+        from rnnoise_amd import capi
+        model = capi.Model(blob)
+        W = model.weight_bytes
+        batch = capi.Batch(model, N, device=local_rank)
+        batch.set_nn_path(1 if a.nn == "mfma" else 0)
+        # inputs resident in HBM; cycle through at most `cap` distinct frames if K+W is large
+        cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))
+        d_in = synth_pcm_torch(torch, N, cap, dev, seed_base=mine.start)
+        d_out = torch.empty_like(d_in)
+        d_vad = torch.empty((cap, N), device=dev)
+        d_gains = torch.empty((cap, N, 32), device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if a.host_io:
+            h_in = d_in.cpu().pin_memory().numpy()
     esz = N * FRAME * 4
 
     def run(first: int, count: int):
-        f = first
-        left = count
+        f, left = first, count
         while left > 0:
             k = f % cap
             n = min(left, cap - k)
-            batch.process_device(d_out.data_ptr() + k * esz, d_in.data_ptr() + k * esz, d_vad.data_ptr() + k * N * 4,
-                                 d_gains.data_ptr() + k * N * 128, n, stream)
+            if stub:
+                batch.process_device()
+            elif a.host_io:
+                batch.process(h_in[k:k + n], want_gains=False)
+            else:
+                batch.process_device(d_out.data_ptr() + k * esz, d_in.data_ptr() + k * esz, d_vad.data_ptr() + k * N * 4,
+                                     d_gains.data_ptr() + k * N * 128, n, stream)
             f += n
             left -= n
 
     run(0, Wm)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     batch.enable_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(Wm, K)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for r in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        run(Wm + r * K, K)
+        barrier()
+        times.append(time.perf_counter() - t0)
     kms = batch.kernel_ms()
     batch.enable_timing(False)
-
-    from rnnoise_amd.dist import aggregate_throughput
-    frames, dt = aggregate_throughput(float(N * K), dt, dist, dev)
-    value = frames / dt
-
+    times = aggregate_times(times, dist, dev)  # element-wise MAX over ranks
+    frames_per_rep = float(N * K * world)
+    med = statistics.median(times)
+    line = None
     if rank == 0:
-        sane = bool(torch.isfinite(d_out).all().item()) and float(d_vad.max().item()) > 0.0
-        # algorithmic HBM bytes per launch: per-stream traffic x streams; the weights are read from HBM at most
-        # once per launch, whatever the batch (every later tile finds them in L2 / Infinity Cache) -- the
-        # north_star's per-frame W figure is reported separately as weight_roofline
-        per_launch = {"analysis": ANALYSIS_BYTES * N, "network": W + NETWORK_STATE_BYTES * N, "synthesis": SYNTHESIS_BYTES * N}
-        dom = max(("analysis", "network", "synthesis"), key=lambda k: kms[k])
-        ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        kname = f"rn_{dom}_kernel" if dom != "network" else f"rn_nn_{a.nn}_kernel"
+        sane = True
+        if not stub and not a.host_io:
+            sane = bool(torch.isfinite(d_out).all().item()) and float(d_vad.max().item()) > 0.0
+        kinds = ("highpass", "analysis", "network", "synthesis")
+        per_launch = {k: ALG_BYTES[k] * N + (W if k == "network" else 0) for k in kinds}
+        dom = max(kinds, key=lambda k: kms[k])
+        kname = KERNEL_OF[dom] if (dom != "network" or a.nn == "mfma") else "rn_nn_vector_kernel"
         if dom == "analysis" and 3072 <= N < 24576 and os.environ.get("RNNOISE_AMD_K1_LEAN", "1") != "0":
             kname = "rn_analysis_lean_kernel"  # same code held to 80 VGPRs (dsp_kernels.hip: RN_K1_LEAN_MIN/MAX_STREAMS)
+        ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        pmc = pmc_record(kname, N) or {}
+        traffic = int(pmc["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pmc else None
         line = {
-            "metric": "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": a.gpus, "steps": K, "warmup": Wm,
-            "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC if not stub else "LAUNCHER SELF-TEST (stub batch, no GPU work)",
+            "value": round(frames_per_rep / med, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * med / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8 weights x u8 activations (i32 accumulate) + f32/f64 DSP",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {N} concurrent streams per GPU, default architecture "
-                                   f"(conv 65x3->128->384, 3xGRU(384) block-sparse int8, density 1/3), synthetic "
-                                   f"exporter-made model, network path = {a.nn}",
-                       "streams_per_gpu": N, "frames_per_step": N * a.gpus, "nn_path": a.nn,
-                       "outputs_sane": sane},
-            "roofline": {"bound": "hbm", "kernel": kname + (" (+rn_hp_kernel)" if dom == "analysis" else ""),
-                         "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": measured_traffic(kname, N),
+            "value_min": round(frames_per_rep / max(times), 1), "value_max": round(frames_per_rep / min(times), 1),
+            "repeats": R,
+            "config": {"workload": workload_name(a, N), "streams_per_gpu": N, "frames_per_step": N * world,
+                       "nn_path": a.nn, "model": a.model, "outputs_sane": sane,
+                       "stream_ids_rank0": [mine.start, mine.stop]},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch[dom],
-                         "kernel_ms": {k: round(kms[k], 4) for k in ("analysis", "network", "synthesis")}},
-            "weight_roofline": {"W_bytes_per_frame": W, "frac": round(value * W / (a.gpus * HBM_PEAK), 5),
-                                "definition": "frames/s x W / (n_gpus x 8.0e12 B/s), north_star / SURVEY 8d"},
+                         "kernel_ms": {k: round(kms[k], 4) for k in kinds},
+                         "note": "dominant kernel by HIP-event time inside the timed region; it is issue/latency-bound, "
+                                 "not HBM-bound: see roofline_valu"},
+            # whole step against HBM: mandatory bytes of all four kernels / step time
+            "roofline_step": {"bound": "hbm", "achieved": round(sum(per_launch.values()) / (med / K) / 1e9, 2),
+                              "unit": "GB/s", "frac": round(sum(per_launch.values()) / (med / K) / HBM_PEAK, 5),
+                              "algorithmic_bytes_per_step": sum(per_launch.values())},
+            "weight_roofline": {"W_bytes_per_frame": W, "frac": round(frames_per_rep / med * W / (world * HBM_PEAK), 5),
+                                "definition": "frames/s x W / (n_gpus x 8.0e12 B/s), north_star / SURVEY 8d; weights are "
+                                              "L2-served, so this normalised figure may exceed 1"},
         }
-        if a.gpus == 1 and not a.no_cpu_baseline:
+        if "valu_per_wave" in pmc and kms[dom] > 0:
+            # VALU-issue bound: instructions x 2 clk (wave64 on a SIMD-32) spread over 1024 SIMDs at 2.4 GHz
+            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * 2 / N_SIMD / CLOCK_HZ
+            line["roofline_valu"] = {"bound": "valu-issue", "kernel": kname, "valu_insts_per_wave": pmc["valu_per_wave"],
+                                     "waves": waves_per_launch(dom, N), "issue_bound_ms": round(1e3 * t_issue, 4),
+                                     "frac": round(t_issue / (kms[dom] * 1e-3), 4), "source": pmc.get("source", "profiles/")}
+        if stub:
+            line["stub"] = True
+        if world == 1 and not a.no_cpu_baseline and not stub:
             cb = cpu_baseline(blob)
             if cb:
                 line["cpu_baseline"] = cb
-        print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    return line
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=25, help="repetitions of the K-step timed region (median reported)")
+    ap.add_argument("--streams", type=int, default=65536, help="concurrent streams PER GPU (configs[2]: 65536)")
+    ap.add_argument("--model", choices=["default", "little"], default="default")
+    ap.add_argument("--nn", choices=["vector", "mfma"], default=os.environ.get("RNNOISE_AMD_NN", "mfma"),
+                    help="network path: batched MFMA (default) or the v_dot4 vector path; identical bits")
+    ap.add_argument("--host-io", action="store_true", help="feed host buffers through rnnoise_batch_process (PCIe-inclusive)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher self-test on CPU (gloo)
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and a.gpus > 1:
+        sys.exit(relaunch_under_torchrun(a))
+    line = bench_rank(a)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

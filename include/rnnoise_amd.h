@@ -89,11 +89,15 @@ RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, in
  * call arms the taps (dst may be NULL); later calls copy the last step's record. Tests only. */
 RNNOISE_EXPORT int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst);
 
+/* Test tap: out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on `device` (src/denoise.c:383 is the one libm call
+ * of the path whose device implementation differs from the host's). Host buffers. 0 / -1. */
+RNNOISE_EXPORT int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n);
+
 /* Average device time per launch of each kernel over the calls since the last query, in
  * milliseconds, measured with HIP events on the launch stream when timing is enabled.
- * ms[0]=analysis, ms[1]=network, ms[2]=synthesis. */
+ * ms[0]=analysis (K1), ms[1]=network (K2), ms[2]=synthesis (K3), ms[3]=high-pass + pitch LPC (K0). */
 RNNOISE_EXPORT int rnnoise_batch_enable_timing(RNNoiseBatch *b, int on);
-RNNOISE_EXPORT int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[3], long *launches);
+RNNOISE_EXPORT int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[4], long *launches);
 
 #ifdef __cplusplus
 }

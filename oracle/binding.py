@@ -100,6 +100,7 @@ class Oracle(_FrameRunner):
                 getattr(L, f).restype = C.c_float
                 getattr(L, f).argtypes = [C.c_float]
             L.rno_quantize_u8.argtypes = [C.POINTER(C.c_ubyte), C.POINTER(C.c_float), C.c_int]
+            L.rno_log_energy.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
             cls._lib = L
         return cls._lib
 
@@ -136,6 +137,14 @@ class Oracle(_FrameRunner):
         self.state[:] = s
 
     # stage helpers -----------------------------------------------------------------------
+    @classmethod
+    def log_energy(cls, ex: np.ndarray) -> np.ndarray:
+        """(float)log10(1e-2 + (double)ex) with the host libm (src/denoise.c:383)"""
+        ex = np.ascontiguousarray(ex, np.float32)
+        out = np.empty_like(ex)
+        cls.lib().rno_log_energy(_fp(out), _fp(ex), ex.size)
+        return out
+
     @classmethod
     def fft(cls, x_ri: np.ndarray) -> np.ndarray:
         x_ri = np.ascontiguousarray(x_ri, np.float32)

@@ -846,6 +846,12 @@ static void pitch_filter(cpx *X, const cpx *P, const float *Ex, const float *Ep,
   }
 }
 
+/* the one libm call of the feature path whose GPU counterpart is a different implementation (ocml vs glibc):
+ * (float)log10(1e-2 + (double)Ex), src/denoise.c:383 -- exposed so that a test can sweep it against the device */
+void rno_log_energy(float *out, const float *Ex, int n) {
+  for (int i = 0; i < n; i++) out[i] = (float)log10(1e-2 + Ex[i]);
+}
+
 void rno_state_init(float *st) { memset(st, 0, RN_STATE_FLOATS * sizeof(float)); }
 
 /* rnn_frame_analysis (src/denoise.c:332-345) on an explicit 480-sample analysis memory.

@@ -32,7 +32,7 @@ EXPORTS = [
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
-    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
         L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
         L.rnnoise_batch_train_features.argtypes = [vp, fp, fp, fp, fp, ip, ip, ip, C.c_int]
         L.rnnoise_batch_train_features_device.argtypes = [vp] * 8 + [C.c_int, vp]
+        L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         _lib = L
@@ -218,11 +219,11 @@ class Batch:
         lib().rnnoise_batch_enable_timing(self.h, int(on))
 
     def kernel_ms(self):
-        ms = (C.c_double * 3)()
+        ms = (C.c_double * 4)()
         n = C.c_long(0)
         if lib().rnnoise_batch_kernel_ms(self.h, ms, C.byref(n)):
             raise RuntimeError("kernel_ms failed")
-        return dict(analysis=ms[0], network=ms[1], synthesis=ms[2], launches=n.value)
+        return dict(analysis=ms[0], network=ms[1], synthesis=ms[2], highpass=ms[3], launches=n.value)
 
 
 class DenoiseState:

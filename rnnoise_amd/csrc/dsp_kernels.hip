@@ -1148,10 +1148,21 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   }
 }
 
+// test tap: the log-energy expression of the feature stage (src/denoise.c:383) on arbitrary inputs, so that a sweep can
+// measure how often ocml's log10 and the host libm's round a float differently (DESIGN.md section 2 "known residuals")
+extern "C" __global__ void rn_log_energy_kernel(const float *__restrict__ ex, float *__restrict__ out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = (float)log10(1e-2 + (double)ex[i]);
+}
+extern "C" hipError_t rn_launch_log_energy(const float *ex, float *out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(rn_log_energy_kernel, dim3(1024), dim3(256), 0, st, ex, out, n);
+  return hipGetLastError();
+}
+
 // host-visible launch helpers -----------------------------------------------------------------
 // K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st, hipEvent_t done) {
-  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, (hipEvent_t) nullptr, done, *g, in, slot, 1);
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
+  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, in, slot, 1);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st,

@@ -5,12 +5,12 @@
 //   owns one stream-frame reads and writes contiguous, coalesced rows, and the batched
 //   network kernel sees (streams x features) row-major matrices.
 //   The spectra that the reference copies into delayed_* every frame
-//   (src/denoise.c:498-502) live in a 2-slot ping-pong indexed by frame parity instead:
-//   the analysis kernel writes slot[parity], the synthesis kernel reads slot[parity^1]
-//   as "delayed" -- no copy.
+//   (src/denoise.c:498-502) rotate through RN_SPEC_SLOTS = 3 slots instead: the analysis
+//   kernel of frame t writes slot t%3, the synthesis kernel of frame t reads slot (t-1)%3
+//   as "delayed" -- no copy -- and the third slot lets analysis(t+1) overlap synthesis(t).
 //   analysis_mem (src/denoise.c:73) is not stored: it always equals the last 480 samples
-//   of the previous pitch_buf (both are the previous high-passed frame), which the
-//   analysis kernel has in LDS anyway.
+//   of the previous pitch_buf (both are the previous high-passed frame), which sit in
+//   the pitch ring (RN_RING_SLOTS = 6 slots of 480 samples = 2880 floats per stream).
 #pragma once
 #include <stdint.h>
 #include "../../include/rn_layout.h"
@@ -38,7 +38,7 @@ struct RnTablesDev {
   double dct_scale;           // sqrt(2./22), src/denoise.c:168
 };
 
-// one linear layer of the network, repacked for the GPU (see model.cpp)
+// one linear layer of the network, repacked for the GPU (shim.cpp: stage_linear)
 struct RnLinearDev {
   const float *bias;      // float layers: bias; int8 layers: subias (x86 profile, nnet_arch.h:145-147)
   const float *fw;        // float weights, column-major W[j*N + i]
@@ -61,7 +61,7 @@ struct RnGroupDev {
   int n_streams;
   // persistent per-stream state
   float *mem_hp;       // [N][2]
-  float *pitch_ring;   // [N][1920] ring of high-passed frames; pitch_buf (src/denoise.c:76) = its latest 1728 samples
+  float *pitch_ring;   // [N][RN_RING_SIZE = 2880] ring of high-passed frames; pitch_buf (src/denoise.c:76) = its latest 1728 samples
   float *synth_mem;    // [N][480]
   float *last_gain;    // [N]
   int *last_period;    // [N]

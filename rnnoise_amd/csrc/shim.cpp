@@ -18,7 +18,7 @@
 #include "rcp_lut_x86.h"
 #include "rn_dev.h"
 
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t, hipEvent_t);
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t, hipEvent_t,
                                           hipEvent_t);
@@ -29,7 +29,29 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                         hipEvent_t);
 extern "C" int rn_nn_mfma_available(void);
+extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
 
+
+// Every entry point works on the batch's device and leaves the calling thread's current device as it found it
+// (a host thread may be driving another GPU: torch on cuda:0 beside a batch on device 1).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == device) || hipSetDevice(device) == hipSuccess;
+    if (prev == device) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define ON_DEVICE(dev)                                                                                 \
+  DeviceGuard guard_(dev);                                                                             \
+  if (!guard_.ok) {                                                                                    \
+    fprintf(stderr, "[rnnoise_amd] cannot select HIP device %d (%s:%d)\n", (dev), __FILE__, __LINE__);  \
+    return -1;                                                                                         \
+  }
 
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
@@ -122,7 +144,7 @@ bool linear_from_blob(HostLinear &l, const std::vector<BlobRecord> &recs, const 
     const int32_t *idx = l.idx;
     while (remain > 0) {
       int nb = *idx++;
-      if (nb < 0 || remain < nb + 1) return false;
+      if (nb < 0 || nb > remain - 1) return false;  // (remain < nb + 1 would overflow for nb == INT_MAX)
       for (int i = 0; i < nb; i++) {
         int pos = *idx++;
         if (pos < 0 || pos + 3 >= nin || (pos & 3)) return false;
@@ -235,11 +257,9 @@ DevLinearOffsets stage_linear(Staging &st, const HostLinear &l) {
                 dense[(size_t)(16 * rt + (lane & 15)) * l.nin + 64 * kt + 16 * (lane >> 4) + e];
     o.wmf = st.add(frag.data(), frag.size());
   }
-  if (idx || true) {
-    o.grp = st.add(grp.data(), 4 * grp.size());
-    o.cols = st.add(cols.data(), 2 * cols.size());
-    o.has_cols = l.idx != nullptr;
-  }
+  o.grp = st.add(grp.data(), 4 * grp.size());
+  o.cols = st.add(cols.data(), 2 * cols.size());
+  o.has_cols = l.idx != nullptr;
   if (l.diag) {
     o.diag = st.add(l.diag, 4 * l.nout);
     o.has_diag = true;
@@ -326,7 +346,7 @@ int tables_for_device(int device, RnTablesDev &out) {
          o_br = st.add(bitrev.data(), 2 * bitrev.size());
   DeviceTables t;
   t.device = device;
-  HIP_OK(hipSetDevice(device));
+  ON_DEVICE(device);
   HIP_OK(hipMalloc(&t.mem, st.bytes.size()));
   HIP_OK(hipMemcpy(t.mem, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
   const uint8_t *base = static_cast<const uint8_t *>(t.mem);
@@ -396,7 +416,7 @@ struct RNNoiseBatch {
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
   std::vector<Ev> pending, pool;
-  double ms_sum[3] = {0, 0, 0};
+  double ms_sum[4] = {0, 0, 0, 0};  // analysis, network, synthesis, high-pass
   long launches = 0;
 };
 
@@ -433,7 +453,7 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
   DevLinearOffsets od = stage_linear(st, h.dense_out), ov = stage_linear(st, h.vad_dense);
   DeviceModel d;
   d.device = device;
-  HIP_OK(hipSetDevice(device));
+  ON_DEVICE(device);
   HIP_OK(hipMalloc(&d.mem, st.bytes.size()));
   HIP_OK(hipMemcpy(d.mem, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
   const uint8_t *base = static_cast<const uint8_t *>(d.mem);
@@ -513,8 +533,15 @@ struct TimedLaunch {
       ev = b->pool.back();
       b->pool.pop_back();
     } else {
-      hipEventCreateWithFlags(&ev.a, hipEventDisableSystemFence);  // timing only: no cache writeback / invalidation
-      hipEventCreateWithFlags(&ev.b, hipEventDisableSystemFence);
+      // timing only: no cache writeback / invalidation at the event
+      if (hipEventCreateWithFlags(&ev.a, hipEventDisableSystemFence) != hipSuccess ||
+          hipEventCreateWithFlags(&ev.b, hipEventDisableSystemFence) != hipSuccess) {
+        fprintf(stderr, "[rnnoise_amd] cannot create timing events; this launch is not timed\n");
+        if (ev.a) hipEventDestroy(ev.a);
+        ev.a = ev.b = nullptr;
+        on = false;
+        return;
+      }
     }
     ev.kind = kind;
   }
@@ -557,7 +584,8 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   }
   RnGroupDev probe{};
   b->arena_bytes = batch_layout(probe, nullptr, n_streams);
-  if (hipSetDevice(device) != hipSuccess || hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) {
+  DeviceGuard guard(device);
+  if (!guard.ok || hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) {
     fprintf(stderr, "[rnnoise_amd] cannot allocate %zu bytes of HBM for %d streams\n", b->arena_bytes, n_streams);
     delete b;
     return nullptr;
@@ -580,7 +608,7 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
 
 extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (!b) return;
-  hipSetDevice(b->device);
+  DeviceGuard guard(b->device);
   hipDeviceSynchronize();
   for (auto &e : b->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : b->pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -603,7 +631,7 @@ extern "C" int rnnoise_batch_size(const RNNoiseBatch *b) { return b ? b->n : -1;
 
 extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   if (!b) return -1;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
   b->parity = 0;
   b->ring_slot = 0;
@@ -623,7 +651,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
                                             float *d_gains, int n_frames, void *hip_stream) {
   if (!b || !d_out || !d_in || n_frames < 0) return -1;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   const size_t N = b->n;
   // Multi-frame calls are software-pipelined over three streams: C runs the high-pass of frames up to
   // f+2, B the analysis of frame f+1, A (the caller's stream) network + synthesis of frame f.
@@ -672,8 +700,10 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     // completion events ride in the dispatch packets (stop event of hipExtLaunchKernel): no record packets between
     // the kernels of a stream
     if (pipelined && f >= 3) HIP_OK(hipStreamWaitEvent(sc, b->cur_k1[(f - 3) & 7], 0));
-    b->cur_hp[f & 7] = pipelined ? b->own_hp[f & 7] : nullptr;
-    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc, b->cur_hp[f & 7]));
+    TimedLaunch t(b, 3);
+    b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
+    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
+                        b->cur_hp[f & 7]));
     return 0;
   };
   auto analysis = [&](int f) -> int {  // K1 of frame f on stream sb
@@ -727,7 +757,7 @@ extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *i
                                      int n_frames) {
   if (!b || !out || !in || n_frames < 0) return -1;
   if (n_frames == 0) return 0;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   const size_t N = b->n;
   if (b->stage_frames < n_frames) {
     if (b->stage_in) { hipFree(b->stage_in); hipFree(b->stage_out); hipFree(b->stage_vad); hipFree(b->stage_gains); }
@@ -757,7 +787,7 @@ extern "C" int rnnoise_batch_train_features_device(RNNoiseBatch *b, float *d_rec
   if (!b || !d_records || !d_clean || !d_noisy || !d_vad || !d_lowpass || !d_band_lp || !d_noise_free || n_frames < 0)
     return -1;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   const size_t N = b->n;
   for (int f = 0; f < n_frames; f++) {
     RnTrainArgs tr;
@@ -779,7 +809,7 @@ extern "C" int rnnoise_batch_train_features(RNNoiseBatch *b, float *records, con
                                             const float *vad, const int *lowpass, const int *band_lp,
                                             const int *noise_free, int n_frames) {
   if (!b || !records || !clean || !noisy || !vad || !lowpass || !band_lp || !noise_free || n_frames <= 0) return -1;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   const size_t N = b->n, fb = (size_t)n_frames * N * RN_FRAME_SIZE * 4;
   char *dev = nullptr;
   const size_t o_clean = 0, o_noisy = fb, o_vad = 2 * fb, o_rec = o_vad + (size_t)n_frames * N * 4,
@@ -808,7 +838,7 @@ extern "C" int rnnoise_batch_train_features(RNNoiseBatch *b, float *records, con
 
 extern "C" int rnnoise_batch_export_state(RNNoiseBatch *b, int s, float *f) {
   if (!b || !f || s < 0 || s >= b->n) return -1;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
@@ -840,7 +870,7 @@ extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f
     fprintf(stderr, "[rnnoise_amd] import_state: analysis_mem differs from the tail of pitch_buf\n");
     return -1;
   }
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
   const RnGroupDev &g = b->g;
   const size_t S = s, N = b->n;
@@ -878,7 +908,7 @@ extern "C" long rnnoise_model_weight_bytes(RNNModel *model) {
 
 extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch) {
   if (!b) return -1;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
   if (features) {
     std::vector<float> tmp((size_t)b->n * 68);
@@ -893,7 +923,7 @@ extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *s
 // pitch stage taps of the last step ([N][RN_DBG_FLOATS]); the first call (dst==NULL) arms them
 extern "C" int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst) {
   if (!b) return -1;
-  HIP_OK(hipSetDevice(b->device));
+  ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
   if (!b->debug_buf) {
     HIP_OK(hipMalloc((void **)&b->debug_buf, (size_t)b->n * RN_DBG_FLOATS * 4));
@@ -904,21 +934,36 @@ extern "C" int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst) {
   return 0;
 }
 
+// out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on the device (host buffers; tests only)
+extern "C" int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n) {
+  if (!out || !ex || n <= 0) return -1;
+  ON_DEVICE(device);
+  float *d = nullptr;
+  HIP_OK(hipMalloc((void **)&d, (size_t)n * 8));
+  int rc = -1;
+  if (hipMemcpy(d, ex, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+      rn_launch_log_energy(d, d + n, n, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
+      hipMemcpy(out, d + n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = 0;
+  hipFree(d);
+  return rc;
+}
+
 extern "C" int rnnoise_batch_enable_timing(RNNoiseBatch *b, int on) {
   if (!b) return -1;
   if (batch_flush_timing(b)) return -1;
   b->timing = on != 0;
-  b->ms_sum[0] = b->ms_sum[1] = b->ms_sum[2] = 0;
+  for (double &v : b->ms_sum) v = 0;
   b->launches = 0;
   return 0;
 }
 
-extern "C" int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[3], long *launches) {
+extern "C" int rnnoise_batch_kernel_ms(RNNoiseBatch *b, double ms[4], long *launches) {
   if (!b || !ms) return -1;
   if (batch_flush_timing(b)) return -1;
-  for (int k = 0; k < 3; k++) ms[k] = b->launches ? b->ms_sum[k] / b->launches : 0.0;
+  for (int k = 0; k < 4; k++) ms[k] = b->launches ? b->ms_sum[k] / b->launches : 0.0;
   if (launches) *launches = b->launches;
-  b->ms_sum[0] = b->ms_sum[1] = b->ms_sum[2] = 0;
+  for (double &v : b->ms_sum) v = 0;
   b->launches = 0;
   return 0;
 }
@@ -967,7 +1012,7 @@ extern "C" void rnnoise_model_free(RNNModel *model) {
   if (!model) return;
   if (model->scratch) rnnoise_batch_destroy(model->scratch);
   for (auto &d : model->dev) {
-    hipSetDevice(d.device);
+    DeviceGuard guard(d.device);
     hipFree(d.mem);
   }
   if (model->file) fclose(model->file);

@@ -10,43 +10,73 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def test_measured_traffic_resolves_every_kernel_name_bench_can_emit():
+def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
     for n in (1024, 4096, 16384, 65536, 524288 // 8):
-        for k in ("rn_analysis_kernel", "rn_analysis_lean_kernel", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
-            t = bench.measured_traffic(k, n)
-            assert isinstance(t, int) and t > 1000 * n, (k, n, t)
-    assert bench.measured_traffic("rn_analysis_lean_kernel", 4096) == bench.measured_traffic("rn_analysis_kernel", 4096)
-    assert bench.measured_traffic("rn_nn_vector_kernel", 4096) is None  # never profiled with PMC: reported as null
+        for k in ("rn_hp_kernel", "rn_analysis_kernel", "rn_analysis_lean_kernel", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
+            r = bench.pmc_record(k, n)
+            assert r and r["hbm_bytes_per_frame"] > 1000 and r["valu_per_wave"] > 100, (k, n, r)
+    assert bench.pmc_record("rn_nn_vector_kernel", 4096) is None  # never profiled with PMC: traffic is reported as null
 
 
 def test_algorithmic_bytes_match_design_table():
-    # K0 + K1 = 10,784 + 26,144 - (the 1920-float input row is counted once), K3 = 14,352
-    assert bench.ANALYSIS_BYTES == 30000
-    assert bench.SYNTHESIS_BYTES == 14352
-    assert bench.NETWORK_STATE_BYTES == 12696
+    # DESIGN.md section 4
+    assert bench.ALG_BYTES == {"highpass": 10788, "analysis": 26164, "network": 12696, "synthesis": 14352}
+    assert bench.waves_per_launch("analysis", 65536) == 65536 and bench.waves_per_launch("highpass", 65536) == 1024
+    assert bench.waves_per_launch("network", 65536) == 4096 * 8 and bench.waves_per_launch("network", 17) == 16
+
+
+def test_defaults_are_the_largest_single_gpu_config():
+    a = bench.parse_args([])
+    assert a.streams == 65536 and a.gpus == 1 and a.repeats >= 25 and a.nn == "mfma" and a.model == "default"
+    assert "configs[2]" in bench.workload_name(a, a.streams)
+    a = bench.parse_args(["--model", "little", "--streams", "32768"])
+    assert "configs[3]" in bench.workload_name(a, a.streams)
+    a = bench.parse_args(["--gpus", "8"])
+    assert "configs[4]" in bench.workload_name(a, a.streams)
+
+
+def test_usable_cpus_respects_affinity_and_quota(monkeypatch):
+    n = bench.usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    monkeypatch.setattr(bench, "cgroup_cpu_quota", lambda: 3)
+    assert bench.usable_cpus() == min(3, len(os.sched_getaffinity(0)))
+
+
+def _check_line(d, f):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, (f, key)
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # value and ms_per_step describe the same run
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["frames_per_step"] - 1) < 0.01
 
 
 def test_committed_bench_lines_follow_the_contract():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_final_bench_*.json")))
     assert len(files) >= 4
     for f in files:
+        _check_line(json.loads(open(f).read()), f)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_*bench_*.json"))):
         d = json.loads(open(f).read())
-        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                    "vs_baseline", "dtype", "data", "config", "roofline"):
-            assert key in d, (f, key)
-        assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
-        assert "workload" in d["config"] and "model" not in d["config"]
+        _check_line(d, f)
+        assert d["repeats"] >= 5 and d["value_min"] <= d["value"] <= d["value_max"], f
+        # numerator and denominator of the roofline cover the same kernel (round-1 ADVICE): its own bytes / its own time
         r = d["roofline"]
-        assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-        # value and ms_per_step describe the same run
-        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["frames_per_step"] - 1) < 0.01
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r1_final_bench_4096.json")).read())
-    cb = d["cpu_baseline"]
-    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+        kind = {"rn_hp_kernel": "highpass", "rn_analysis_kernel": "analysis", "rn_analysis_lean_kernel": "analysis",
+                "rn_nn_mfma_kernel": "network", "rn_nn_vector_kernel": "network", "rn_synthesis_kernel": "synthesis"}[r["kernel"]]
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"][kind] * 1e-3) / 1e9) < 0.02 * r["achieved"]
+        if d["n_gpus"] == 1 and "cpu_baseline" in d:
+            cb = d["cpu_baseline"]
+            assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+            assert cb["one_thread_frames_per_s"] > 0 and cb["frames_per_s_per_core"] > 0
 
 
 def test_rocprof_summary_lists_the_kernels_of_the_step():
-    txt = open(os.path.join(ROOT, "profiles", "r1_final_kernel_stats.txt")).read()
-    for k in ("rn_hp_kernel", "rn_analysis", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
-        assert k in txt
+    for f in ["r1_final_kernel_stats.txt"] + [os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r2_*kernel_stats*.txt"))]:
+        txt = open(os.path.join(ROOT, "profiles", f)).read()
+        for k in ("rn_hp_kernel", "rn_analysis", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
+            assert k in txt, (f, k)

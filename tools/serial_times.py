@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone kernel durations: the four kernels of a frame step run back to back on ONE stream
-(single-frame calls switch the 3-stream pipeline off), HIP events around K1/K2/K3; K0 = the rest.
+(single-frame calls switch the 3-stream pipeline off), HIP events around each of K0/K1/K2/K3.
 
 usage: tools/serial_times.py [streams ...]     (needs a GPU; bench.py reports the pipelined numbers)
 """
@@ -40,7 +40,7 @@ for N in [int(x) for x in sys.argv[1:]] or [4096, 65536]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
     k = b.kernel_ms()
-    rest = dt - k["analysis"] - k["network"] - k["synthesis"]
-    print(f"N={N}: step {dt:.4f} ms serial | K1 {k['analysis']:.4f}  K2 {k['network']:.4f}  K3 {k['synthesis']:.4f}  "
-          f"K0+launch gaps {rest:.4f}")
+    rest = dt - k["analysis"] - k["network"] - k["synthesis"] - k["highpass"]
+    print(f"N={N}: step {dt:.4f} ms serial | K0 {k['highpass']:.4f}  K1 {k['analysis']:.4f}  K2 {k['network']:.4f}  "
+          f"K3 {k['synthesis']:.4f}  launch gaps {rest:.4f}")
     b.close()
