@@ -70,7 +70,8 @@ KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "netw
 
 
 def waves_per_launch(kind: str, n_streams: int) -> int:
-    return {"highpass": -(-n_streams // 64), "analysis": n_streams, "network": -(-n_streams // 16) * 8,
+    return {"highpass": -(-n_streams // 64), "analysis": -(-n_streams // 4) * 4 if n_streams >= 6144 else n_streams,
+            "network": -(-n_streams // 16) * 8,
             "synthesis": n_streams}[kind]
 
 
@@ -112,7 +113,7 @@ def pmc_record(kernel: str, n_streams: int):
         with open(os.path.join(ROOT, "profiles", "pmc_by_streams.json")) as f:
             sets = json.load(f)["by_streams"]
         k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]
-        return k.get(kernel) or k.get(kernel.replace("_lean", ""))
+        return k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", ""))
     except Exception:
         return None
 
@@ -331,8 +332,8 @@ def bench_rank(a) -> dict | None:
         per_launch = {k: ALG_BYTES[k] * N + (W if k == "network" else 0) for k in kinds}
         dom = max(kinds, key=lambda k: kms[k])
         kname = KERNEL_OF[dom] if (dom != "network" or a.nn == "mfma") else "rn_nn_vector_kernel"
-        if dom == "analysis" and 3072 <= N < 24576 and os.environ.get("RNNOISE_AMD_K1_LEAN", "1") != "0":
-            kname = "rn_analysis_lean_kernel"  # same code held to 80 VGPRs (dsp_kernels.hip: RN_K1_LEAN_MIN/MAX_STREAMS)
+        if dom == "analysis" and N < 6144:
+            kname = "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
         ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         pmc = pmc_record(kname, N) or {}
         traffic = int(pmc["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pmc else None

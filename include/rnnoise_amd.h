@@ -89,6 +89,13 @@ RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, in
  * call arms the taps (dst may be NULL); later calls copy the last step's record. Tests only. */
 RNNOISE_EXPORT int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst);
 
+/* Test tap: n independent 960-point transforms through the register-resident FFT of the analysis / synthesis kernels
+ * (rnnoise_amd/csrc/fft_reg.h; reference: rnn_fft_c, src/kiss_fft.c:566-586), `reps` passes each with the spectrum fed
+ * back as the next input.  in/out: [n][960][2] host floats, natural order.  variant 0/1 = exchange implementation.
+ * clocks[n] (optional): shader clocks per wave; xlane[2][6][64] (optional): source lanes of the exchange primitives. */
+RNNOISE_EXPORT int rnnoise_amd_debug_fft(int device, int variant, float *out, const float *in, int n, int reps,
+                                         unsigned long long *clocks, int *xlane);
+
 /* Test tap: out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on `device` (src/denoise.c:383 is the one libm call
  * of the path whose device implementation differs from the host's). Host buffers. 0 / -1. */
 RNNOISE_EXPORT int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n);

@@ -32,7 +32,7 @@ EXPORTS = [
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
-    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.rnnoise_batch_train_features.argtypes = [vp, fp, fp, fp, fp, ip, ip, ip, C.c_int]
         L.rnnoise_batch_train_features_device.argtypes = [vp] * 8 + [C.c_int, vp]
         L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
+        L.rnnoise_amd_debug_fft.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), ip]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         _lib = L

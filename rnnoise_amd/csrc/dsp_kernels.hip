@@ -11,12 +11,24 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "rn_dev.h"
+#include "fft_reg.h"
 
 #define WAVE 64
-#define RN_K1_LEAN_MIN_STREAMS 3072  // see rn_analysis_lean_kernel
-#define RN_K1_LEAN_MAX_STREAMS 24576
+#define RN_K1_MULTI_MIN_STREAMS 6144  // from here on K1_SPW streams share a workgroup (see rn_analysis_single_kernel)
 
 struct cpx { float r, i; };
+
+// Every LDS arena below belongs to ONE wavefront, and a wavefront's LDS instructions execute in issue order, so the
+// hand-offs between lanes of a wave need no s_barrier: a wavefront-scope fence pins the compiler's ordering and nothing
+// else.  (In a one-wave workgroup __syncthreads() compiles to exactly this; the analysis kernel runs several waves per
+// workgroup and must not make them march in lock-step through every stage.)  Workgroup barriers are spelled
+// __syncthreads() and appear only where one wave works on data of the others (analysis_body: "narrow phases").
+#define RN_WSYNC()                                             \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
 
 __device__ __constant__ int c_eband[RN_NB_BANDS + 2] = {
     0,  2,  4,  6,  8,  10, 12, 15, 18,  21,  24,  28,  32,  36,  41,  47,  53,
@@ -51,7 +63,7 @@ __device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i
 // exact expression tree.  A butterfly's elements are m apart: within one 16-group for m = 1, 4 and
 // whole groups apart otherwise, so the padded distance is a constant (18 per 16, 72 per 64, 216 per 192).
 __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
-  __syncthreads();
+  RN_WSYNC();
   for (int b = lane; b < 240; b += WAVE) {  // radix-4, m=1, twiddle-free (:112-131)
     cpx *p = F + 4 * b + 2 * (b >> 2);
     cpx a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
@@ -64,7 +76,7 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
     p[1] = {s0.r + d.i, s0.i - d.r};
     p[3] = {s0.r - d.i, s0.i + d.r};
   }
-  __syncthreads();
+  RN_WSYNC();
 #pragma unroll
   for (int stage = 0; stage < 2; stage++) {  // radix-4: (m=4, fstride 60), (m=16, fstride 15) (:141-165)
     const int m = stage ? 16 : 4, fs = stage ? 15 : 60;
@@ -83,7 +95,7 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
       p[pm] = {s5.r + s4.i, s5.i - s4.r};
       p[3 * pm] = {s5.r - s4.i, s5.i + s4.r};
     }
-    __syncthreads();
+    RN_WSYNC();
   }
   {  // radix-3, m=64, fstride 5 (:201-225)
     const float epi3i = tw[5 * 64].i;
@@ -101,7 +113,7 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
       p[144] = {fm.r + s0.i, fm.i - s0.r};
       p[72] = {fm.r - s0.i, fm.i + s0.r};
     }
-    __syncthreads();
+    RN_WSYNC();
   }
   {  // radix-5, m=192, fstride 1 (:269-302)
     const cpx ya = tw[192], yb = tw[384];
@@ -128,7 +140,7 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
       p[432] = cadd(s11, s12);
       p[648] = csub(s11, s12);
     }
-    __syncthreads();
+    RN_WSYNC();
   }
 }
 
@@ -136,47 +148,57 @@ __device__ void fft960_lds(cpx *F, const cpx *__restrict__ tw, int lane) {
 // every bin of band b, (1-frac)*tmp to sum[b] and frac*tmp to sum[b+1]; so accumulator k receives
 // band k-1's `frac` parts in bin order, then band k's `1-frac` parts.  Here all 64 lanes first form
 // the 800 products (each rounded exactly as in the reference) and lay them out so that accumulator
-// k's sequence is contiguous (hi part of bin -> Q[eband[b+1]+bin], lo part -> Q[eband[b]+bin]); then
-// lane k < 34 adds its sequence in order.  Padding steps add +0.0f, which changes no bit.
-// Q: LDS scratch of >= 864 floats; sums: LDS scratch [34].
-// XPAD / PPAD: the operand is an FFT work area (padded layout) rather than a plain array
-template <bool XPAD, bool PPAD>
-__device__ void band_accumulate(float *bandE, const cpx *X, const cpx *P, float *Q, float *sums,
-                                const RnTablesDev &tb, int lane) {
+// k's sequence is contiguous; then lane k < 34 adds its sequence in order.  Padding steps add +0.0f,
+// which changes no bit (a sum that starts at +0 never becomes -0).
+// ---- band energy / correlation from REGISTER-resident spectra (the transform of fft_reg.h leaves lane l with the bins
+// 64*j + fft_pos(l)).  Same arithmetic and per-accumulator order as band_accumulate above; the products go to LDS in the
+// layout of RnTablesDev::band_q -- accumulator k's terms contiguous from a 16-byte aligned slot -- so that the serial sums
+// read four terms per LDS instruction.  NX / NY: array lengths (only bins < 400, j = 0..6, are used).
+template <int NX, int NY>
+__device__ __forceinline__ void band_products(float *Q, const float (&xr)[NX], const float (&xi)[NX], const float (&yr)[NY],
+                                              const float (&yi)[NY], const RnTablesDev &tb, int pos) {
+  const uint32_t *band_q = tb.band_q;  // opaque copies: re-read from L1 at every call rather than kept across the pitch stage
+  const float *band_frac = tb.band_frac;
+  asm volatile("" : "+s"(band_q), "+s"(band_frac));
 #pragma unroll
-  for (int t = 0; t < 7; t++) {  // 400 = 6.25 x 64; constant trip count so that the table / HBM loads overlap
-    const int bin0 = lane + WAVE * t, bin = bin0 < 400 ? bin0 : 399;
-    const int b = tb.band_of_bin[bin];
-    const float frac = tb.band_frac[bin];
-    const cpx x = X[XPAD ? FPAD(bin) : bin], y = P[PPAD ? FPAD(bin) : bin];
-    float tmp = x.r * y.r;
-    tmp += x.i * y.i;
-    Q[c_eband[b + 1] + bin] = frac * tmp;  // lanes past the end redo bin 399 with the same values: no branch
-    Q[c_eband[b] + bin] = (1 - frac) * tmp;
+  for (int j = 0; j < 7; j++) {
+    const int bin = WAVE * j + pos, bc = bin < 400 ? bin : 399;
+    const uint32_t q = band_q[bc];
+    const float frac = band_frac[bc];
+    float tmp = xr[j] * yr[j];
+    tmp += xi[j] * yi[j];
+    if (bin < 400) {
+      Q[(q >> 10) & 0x3ff] = frac * tmp;
+      Q[q & 0x3ff] = (1 - frac) * tmp;
+    }
   }
-  __syncthreads();
+}
+// the 34 serial sums and the band vector (src/denoise.c:104-112); Q as written by band_products
+__device__ __forceinline__ void band_chain(float *bandE, const float *Q, float *sums, const RnTablesDev &tb, int lane) {
+  RN_WSYNC();
   {
-    const int k = lane < RN_NB_BANDS + 2 ? lane : 0;
-    const int lo = k ? c_eband[k - 1] : 0;
-    const int start = lo + c_eband[k];
-    const int len = lane < RN_NB_BANDS + 2 ? (k <= RN_NB_BANDS ? c_eband[k + 1] : 400) - lo : 0;
-    const float *q = Q + start;
+    const uint32_t ch = tb.band_chain[lane < RN_NB_BANDS + 2 ? lane : 0];
+    const int len = lane < RN_NB_BANDS + 2 ? (int)(ch >> 16) : 0;
+    const float4 *q = reinterpret_cast<const float4 *>(Q + (ch & 0xffff));
     float s = 0;
-#pragma unroll 4
-    for (int t = 0; t < 84; t++) {  // longest accumulator: 39 + 44 = 83 terms
-      const float v = q[t];         // start + 83 <= 839 < 864
-      s += (t < len) ? v : 0.f;
+#pragma unroll 3
+    for (int t = 0; t < 21; t++) {  // longest accumulator: 39 + 44 = 83 terms; slots past `len` are not summed
+      const float4 v = q[t];
+      s += (4 * t + 0 < len) ? v.x : 0.f;
+      s += (4 * t + 1 < len) ? v.y : 0.f;
+      s += (4 * t + 2 < len) ? v.z : 0.f;
+      s += (4 * t + 3 < len) ? v.w : 0.f;
     }
     if (lane < RN_NB_BANDS + 2) sums[lane] = s;
   }
-  __syncthreads();
+  RN_WSYNC();
   if (lane < RN_NB_BANDS) {
     float v = sums[lane + 1];
     if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
     if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
     bandE[lane] = v;
   }
-  __syncthreads();
+  RN_WSYNC();
 }
 
 // src/denoise.c:160-170, lane i < 32 produces out[i]; c[j] = rnn_dct_table[j*32 + i], fetched by the
@@ -232,20 +254,23 @@ __device__ __forceinline__ void best_pitch_select(const float *xcorr, const floa
 
 // src/pitch.c:44-102 (float build), restructured so that only the genuinely serial part stays
 // serial:  (1) all lanes form d[i] = y[i+len]^2 - y[i]^2 (each product rounded once, as in the
-// reference);  (2) the running energy Syy -- a float recurrence with a clamp, hence order-bound -- is
-// swept once from the start value Syy0 = 1 + sum_{j<len} y[j]^2 (computed by the caller inside a
-// dot-product pass), 4 steps per LDS transaction, leaving Syy-before-step-i in syy[i];
+// reference) -- fbp_increments;  (2) the running energy Syy -- a float recurrence with a clamp, hence
+// order-bound -- is swept once from the start value Syy0 = 1 + sum_{j<len} y[j]^2 (computed by the
+// caller inside a dot-product pass), 4 steps per LDS transaction, leaving Syy-before-step-i in
+// syy[i] -- fbp_sweep, ONE LANE PER STREAM (see the narrow phases of analysis_body);
 // (3) best_pitch_select.  Used for the coarse (4x decimated) search; the fine search shares its sweep
 // with yy_lookup (energy_sweeps below).  syy: scratch >= max_pitch rounded up to 4.
-__device__ void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, float Syy0, float *syy,
-                                int &bp0, int &bp1, int lane) {
+__device__ __forceinline__ void fbp_increments(const float *y, int len, int max_pitch, float *syy, int lane) {
   const int mp4 = (max_pitch + 3) & ~3;
   for (int i = lane; i < mp4; i += WAVE) {
     const float a = (i + len < len + max_pitch) ? y[i + len] : 0.f, b = y[i];
     syy[i] = a * a - b * b;
   }
+}
+// lane-private: every participating lane sweeps the syy[] of ITS stream (pointer and start value differ per lane)
+__device__ __forceinline__ void fbp_sweep(float *syy, int max_pitch, float Syy0, bool store) {
+  const int mp4 = (max_pitch + 3) & ~3;
   float Syy = Syy0;
-  __syncthreads();
   for (int i = 0; i < mp4; i += 4) {
     const float4 d = *reinterpret_cast<const float4 *>(syy + i);
     float4 o;
@@ -253,11 +278,8 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
     o.y = Syy; Syy = fmaxf(1.f, Syy + d.y);
     o.z = Syy; Syy = fmaxf(1.f, Syy + d.z);
     o.w = Syy; Syy = fmaxf(1.f, Syy + d.w);
-    if (lane == 0) *reinterpret_cast<float4 *>(syy + i) = o;
+    if (store) *reinterpret_cast<float4 *>(syy + i) = o;
   }
-  __syncthreads();
-  best_pitch_select(xcorr, syy, max_pitch, bp0, bp1, lane);
-  __syncthreads();
 }
 
 // The two long running-energy recurrences of the pitch stage, swept TOGETHER (lane 0 / lane 1 of the
@@ -273,8 +295,7 @@ __device__ void find_best_pitch(const float *xcorr, const float *y, int len, int
 // A_i = rsq[479+i], B_i = rsq[i-1].  Results overwrite the A operand just consumed: afterwards
 // Syy-before-lag-i = D[i-1] (D[-1] = syy0)  and  yy_lookup[i] = rsq[479+i] (rsq[479] = xx), clamped
 // at 0 by a parallel pass.  D: 16-byte aligned, D[-1..295]; zero4: 4 floats.
-__device__ __forceinline__ void energy_sweeps(const float *xlp, float *rsq, float *D, float *zero4, float syy0,
-                                              float xx, int lane) {
+__device__ __forceinline__ void energy_sweeps_prepare(const float *xlp, float *rsq, float *D, float *zero4, int lane) {
   for (int k = lane; k < 864; k += WAVE) {
     const float v = xlp[863 - k];
     rsq[k] = v * v;
@@ -284,33 +305,35 @@ __device__ __forceinline__ void energy_sweeps(const float *xlp, float *rsq, floa
     D[i] = a * a - b * b;
   }
   if (lane < 4) zero4[lane] = 0.f;
-  __syncthreads();
-  if (lane == 0) D[-1] = syy0;
-  if (lane == 1) rsq[479] = xx;
-  {
-    float s = (lane == 0) ? syy0 : xx;
-    float *pa = (lane == 0) ? D : rsq + 480;
-    const float *pb = (lane == 0) ? zero4 : rsq;
-    const int sb = (lane == 0) ? 0 : 4;
-    const float lo = (lane == 0) ? 1.f : -__builtin_inff();
-    float4 a = *reinterpret_cast<const float4 *>(pa), b = *reinterpret_cast<const float4 *>(pb);
-    for (int j = 0; j < 384; j += 4) {
-      pb += sb;
-      const float4 an = *reinterpret_cast<const float4 *>(pa + j + 4);  // last one reads past the operands; unused
-      const float4 bn = *reinterpret_cast<const float4 *>(pb);
-      float4 o;
-      s = fmaxf(lo, (s + a.x) - b.x); o.x = s;
-      s = fmaxf(lo, (s + a.y) - b.y); o.y = s;
-      s = fmaxf(lo, (s + a.z) - b.z); o.z = s;
-      s = fmaxf(lo, (s + a.w) - b.w); o.w = s;
-      if (lane == 1 || (lane == 0 && j < 296)) *reinterpret_cast<float4 *>(pa + j) = o;
-      a = an;
-      b = bn;
-    }
+}
+// One lane per recurrence: role 0 = Syy of the fine search, role 1 = yy_lookup; the arrays are those of the lane's OWN
+// stream (several streams' recurrences advance in one wave, see the narrow phases of analysis_body).
+__device__ __forceinline__ void energy_sweeps_run(float *rsq, float *D, const float *zero4, float syy0, float xx, int role,
+                                                  bool on) {
+  if (on && role == 0) D[-1] = syy0;
+  if (on && role == 1) rsq[479] = xx;
+  float s = (role == 0) ? syy0 : xx;
+  float *pa = (role == 0) ? D : rsq + 480;
+  const float *pb = (role == 0) ? zero4 : rsq;
+  const int sb = (role == 0) ? 0 : 4;
+  const float lo = (role == 0) ? 1.f : -__builtin_inff();
+  float4 a = *reinterpret_cast<const float4 *>(pa), b = *reinterpret_cast<const float4 *>(pb);
+  for (int j = 0; j < 384; j += 4) {
+    pb += sb;
+    const float4 an = *reinterpret_cast<const float4 *>(pa + j + 4);  // last one reads past the operands; unused
+    const float4 bn = *reinterpret_cast<const float4 *>(pb);
+    float4 o;
+    s = fmaxf(lo, (s + a.x) - b.x); o.x = s;
+    s = fmaxf(lo, (s + a.y) - b.y); o.y = s;
+    s = fmaxf(lo, (s + a.z) - b.z); o.z = s;
+    s = fmaxf(lo, (s + a.w) - b.w); o.w = s;
+    if (on && (role == 1 || j < 296)) *reinterpret_cast<float4 *>(pa + j) = o;
+    a = an;
+    b = bn;
   }
-  __syncthreads();
+}
+__device__ __forceinline__ void energy_sweeps_clamp(float *rsq, int lane) {
   for (int i = 1 + lane; i <= 384; i += WAVE) rsq[479 + i] = fmaxf(0.f, rsq[479 + i]);  // MAX32(0, yy)
-  __syncthreads();
 }
 
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
@@ -326,167 +349,6 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // 
       clk_prev = now_;                                                       \
     }                                                                        \
   } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// K0: rnn_biquad (src/denoise.c:409-419, coefficients :469-470), transposed: lane = stream.
-// The recurrence is strictly serial per stream (every step rounds its state to float), so the
-// wave-per-frame kernel would idle 63 of 64 lanes for 480 steps; here 64 streams advance in
-// lock-step instead.  Output goes straight into the stream's pitch ring (slot `slot`).
-// a0*yi and a1*yi are products of two 24-bit significands, exact in double, so
-// fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
-// ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp) {
-  const int s = blockIdx.x * WAVE + threadIdx.x;
-  if (s >= g.n_streams) return;
-  const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
-  const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
-  float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
-  const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
-  float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
-  // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
-  // filtered: with one wave per SIMD nothing else hides the HBM round trip
-  constexpr int BLK = 8;  // float4 per block
-  float4 cur[BLK], nxt[BLK];
-#pragma unroll
-  for (int j = 0; j < BLK; j++) nxt[j] = x[j];
-  for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
-#pragma unroll
-    for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-    if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
-#pragma unroll
-      for (int j = 0; j < BLK; j++) nxt[j] = x[(blk + 1) * BLK + j];
-    }
-#define HP_STEP(xi, yo)                                              \
-    {                                                                \
-      const float yi = (xi) + m0;                                    \
-      const double xd = (double)(xi), yd = (double)yi;               \
-      m0 = (float)((double)m1 + fma(na0, yd, b0d * xd));             \
-      m1 = (float)fma(na1, yd, xd);                                  \
-      (yo) = yi;                                                     \
-    }
-#pragma unroll
-    for (int j = 0; j < BLK; j++) {
-      const float4 v = cur[j];
-      float4 o;
-      if (apply_hp) {
-        HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
-      } else {
-        o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
-      }
-      y[blk * BLK + j] = o;
-    }
-#undef HP_STEP
-  }
-  if (apply_hp) {
-    g.mem_hp[2 * s] = m0;
-    g.mem_hp[2 * s + 1] = m1;
-  }
-
-  // ---- rnn_pitch_downsample's serial half (src/pitch.c:146-214): 2x decimation, 5-lag autocorrelation
-  // (src/celt_lpc.c:92-174), lag window, order-4 Levinson (src/celt_lpc.c:38-89) -> the 5 FIR taps.
-  // In the wave-per-frame kernel these 5 chains of 864 steps used 5 lanes of 64; here every lane
-  // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
-  // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
-  // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
-  {
-    const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
-    const int ring0 = RN_RING0(slot);
-    // pitch_buf in blocks of 32 floats (8 float4); ring0 and the ring size are multiples of 32, so a block never
-    // straddles the wrap; the next block is requested before this one is consumed
-    auto block = [&](int b, float4 (&dst)[BLK]) {
-      int p = ring0 + 32 * b;
-      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
-      const float4 *src = reinterpret_cast<const float4 *>(ring + p);
-#pragma unroll
-      for (int j = 0; j < BLK; j++) dst[j] = src[j];
-    };
-    float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
-    float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
-    float prev = 0;                          // pitch_buf[4c-1]
-    block(0, nxt);
-    for (int b = 0; b < RN_PITCH_BUF_SIZE / 32; b++) {
-#pragma unroll
-      for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-      if (b + 1 < RN_PITCH_BUF_SIZE / 32) block(b + 1, nxt);
-#pragma unroll
-      for (int j = 0; j < BLK; j++) {
-        const int c = b * BLK + j;
-        const float4 v = cur[j];
-        float xl[2];
-        xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
-        xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
-        prev = v.w;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int t = 2 * c + h;
-          const float x0 = xl[h];
-          if (t < 860) {
-            ac[0] = ac[0] + x0 * x0;
-            ac[1] = ac[1] + w1 * x0;
-            ac[2] = ac[2] + w2 * x0;
-            ac[3] = ac[3] + w3 * x0;
-            ac[4] = ac[4] + w4 * x0;
-          } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
-            const int e = t - 860;
-            d[0] = d[0] + x0 * x0;
-            if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
-            if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
-            if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
-            ac[4] = ac[4] + w4 * x0;
-          }
-          w4 = w3; w3 = w2; w2 = w1; w1 = x0;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
-    ac[0] *= 1.0001f;
-#pragma unroll
-    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
-    float lpc[4] = {0, 0, 0, 0};
-    if (ac[0] != 0) {
-      float error = ac[0];
-      bool done = false;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (!done) {
-          float rr = 0;
-#pragma unroll
-          for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-          rr += ac[i + 1];
-          const float r = -rr / error;
-          lpc[i] = r;
-#pragma unroll
-          for (int j = 0; j < (i + 1) >> 1; j++) {
-            const float t1 = lpc[j], t2 = lpc[i - 1 - j];
-            lpc[j] = t1 + r * t2;
-            lpc[i - 1 - j] = t2 + r * t1;
-          }
-          error = error - (r * r) * error;
-          if (error < .001f * ac[0]) done = true;  // `break` (celt_lpc.c:81-82)
-        }
-      }
-    }
-    float tmp = 1.f;
-    const float c1 = .8f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      tmp = .9f * tmp;
-      lpc[i] = lpc[i] * tmp;
-    }
-    float *o = g.lpc2 + ((size_t)slot * g.n_streams + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
-    o[0] = lpc[0] + .8f;
-    o[1] = lpc[1] + c1 * lpc[0];
-    o[2] = lpc[2] + c1 * lpc[1];
-    o[3] = lpc[3] + c1 * lpc[2];
-    o[4] = c1 * lpc[3];
-    if (g.debug) {
-#pragma unroll
-      for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
-    }
-  }
-}
 
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
 // x 16-byte aligned, y arbitrary; both may differ per lane.  The next 8 operand pairs are fetched
@@ -587,22 +449,49 @@ struct AnalysisLds {
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
-// into the pitch ring.  grid = n_streams blocks of one wavefront; ~12 KB of LDS per wave.
+// into the pitch ring.  One wavefront owns one stream-frame and a 10 KB LDS arena; SPW of them form
+// a workgroup (grid = ceil(n_streams / SPW)).
 // `ring0` = physical ring position of pitch_buf[0] (src/denoise.c:359-360 shift = ring rotation).
+//
+// Narrow phases.  Three stretches of the pitch analysis are serial chains that occupy 1, 12 and 2
+// lanes of a wave for 148, 480 and 384 steps (coarse running energy; fine cross-correlations + start
+// energies; fine running energy + yy_lookup) -- a quarter of the kernel's instructions for a few
+// percent of its arithmetic.  A one-lane instruction costs the issue slot of a 64-lane one, so the
+// workgroup's waves meet at a barrier and wave 0 runs those chains for ALL SPW streams side by side
+// (disjoint lane groups, each lane pointing into its own stream's arena) while the other waves wait
+// without issuing anything.  Every chain is still one lane's serial sum in the reference order.
 // ---------------------------------------------------------------------------------------------
-template <bool TRAIN>
+#define K1_SPW 4       // streams (= waves) per workgroup of the inference kernels: 12 fine-search lanes x 4 <= 64
+#define K1_MAIL 8      // floats of mailbox per stream behind the arenas: values handed between a stream's wave and wave 0
+#define MAIL_SYY0C 0   //   start energy of the coarse find_best_pitch
+#define MAIL_BP0 1     //   coarse best lags (int bits)
+#define MAIL_BP1 2
+#define MAIL_XX 3      //   <x, x> of remove_doubling
+#define MAIL_SYY0F 4   //   start energy of the fine find_best_pitch
+template <bool TRAIN, int SPW>
 __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot, int parity,
                                               const RnTrainArgs &tr) {
   const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  AnalysisLds &L = *reinterpret_cast<AnalysisLds *>(smem_raw);
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
+  AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw);
+  float *mailbox = reinterpret_cast<float *>(smem_raw + SPW * sizeof(AnalysisLds));
+  const int wave = SPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, lane = threadIdx.x & (WAVE - 1);
+  AnalysisLds &L = arenas[wave];
+  float *mail = mailbox + wave * K1_MAIL;
+  // a tail workgroup's surplus waves redo the last stream without storing anything: they still meet every barrier
+  const int s_raw = blockIdx.x * SPW + wave;
+  const bool wr = s_raw < g.n_streams;
+  const int s = wr ? s_raw : g.n_streams - 1;
+// workgroup barrier between a stream's own wave and wave 0 (a wavefront fence when the workgroup is one wave)
+#define WG_SYNC()                      \
+  do {                                 \
+    if (SPW > 1) __syncthreads();      \
+    else RN_WSYNC();                   \
+  } while (0)
   float *scr = L.a;
-  cpx *F = reinterpret_cast<cpx *>(L.a);
   float *xlp = scr + SCR_XLP, *Qs = scr + SCR_Q;
   float *sums = scr + SCR_MISC, *Ex = sums + 40, *Ep = Ex + 32, *Exp = Ep + 32, *Ly = Exp + 32;
-  float *dbg = g.debug ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
+  float *dbg = (g.debug && wr) ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
   auto pb_at = [&](int i) {  // pitch_buf[i], i in [0, 1728): ring0 + i < 2 * RN_RING_SIZE, one conditional wrap
@@ -614,26 +503,47 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 
   CLK_TAP(0);
   CLK_TAP(1);
-  // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
+  const int pos = fft_pos(lane);              // this lane's bins after a transform: 64*j + pos
+  const float2 *ftw = reinterpret_cast<const float2 *>(tb.fft_tw);
+  float *S = scr;                             // [960] windowed frame in natural order (FFT phases only)
+  // window [start, start+960) of pitch_buf -> this lane's 15 consecutive scaled samples (fft_reg.h "Input"), through LDS:
+  // the global loads stay coalesced, and the 15-float runs are read back conflict-free (stride 15 is odd)
+  auto window_to_regs = [&](float (&ar)[15], float (&ai)[15], int start, const float *hw) {
 #pragma unroll 5
-  for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
-    const int i = lane + WAVE * t;
-    float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-    float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE + i) * w;
-    F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
-  }
-  fft960_lds(F, tw, lane);
-  if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[FPAD(i)] = {0.f, 0.f};
-    __syncthreads();
-  }
+    for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
+      const int i = lane + WAVE * t;
+      const float w = hw[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
+      S[i] = PB(start + i) * w;
+    }
+    RN_WSYNC();
+    const float *run = S + 15 * fft_lam(lane);
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+      ar[b] = 0.0010416667f * run[fft_c(b)];  // the 1/960 input scale of kiss_fft (src/kiss_fft.c:582)
+      ai[b] = 0.0010416667f * 0.f;
+    }
+    RN_WSYNC();
+  };
+  // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
-  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = F[FPAD(i)];
-    gX[2 * i] = v.r;
-    gX[2 * i + 1] = v.i;
+  {
+    float xr[15], xi[15];
+    window_to_regs(xr, xi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE, tb.half_window);
+    regfft960<RN_FFT_XLANE>(xr, xi, lane, ftw);
+    if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
+      const int lp = tr.lowpass[s];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (WAVE * j + pos >= lp) xr[j] = xi[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int bin = WAVE * j + pos;
+      if (bin < RN_FREQ_SIZE && wr) reinterpret_cast<float2 *>(gX)[bin] = make_float2(xr[j], xi[j]);
+    }
+    band_products(Qs, xr, xi, xr, xi, tb, pos);
   }
-  band_accumulate<true, true>(Ex, F, F, Qs, sums, tb, lane);
+  band_chain(Ex, Qs, sums, tb, lane);
 
   CLK_TAP(2);  // window + FFT(X) + Ex
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
@@ -645,7 +555,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
     xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
   }
-  __syncthreads();
+  RN_WSYNC();
   // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
   float lpc2[5];
 #pragma unroll
@@ -667,14 +577,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       }
       r[t] = sum;
     }
-    __syncthreads();
+    RN_WSYNC();
 #pragma unroll
     for (int t = 0; t < 14; t++) {
       int i = lane + WAVE * t;
       if (i < 864) xlp[i] = r[t];
     }
   }
-  __syncthreads();
+  RN_WSYNC();
 
   CLK_TAP(3);  // downsample + autocorr + LPC + FIR
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
@@ -686,49 +596,82 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   {
     v2f *Z = reinterpret_cast<v2f *>(scr + SCR_Z);
     for (int j = lane; j < 303; j += WAVE) Z[j] = v2f{xlp[2 * j], xlp[2 * j + 128]};
-    __syncthreads();
+    RN_WSYNC();
     // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
     const v2f p = chain_dot8_x2(y4 + 192, Z + lane, 240);
     // lanes 0..18: lags 128..146; lane 19: the start energy 1 + sum y4[j]^2 of the coarse find_best_pitch
     float q = 0;
     if (lane < 20) q = chain_dot8(lane < 19 ? y4 + 192 : y4, lane < 19 ? y4 + lane + 128 : y4, 240, lane < 19 ? 0.f : 1.f);
-    __syncthreads();  // Z is dead; xcorr goes into its area
+    RN_WSYNC();  // Z is dead; xcorr goes into its area
     xc[lane] = p.x;
     xc[lane + 64] = p.y;
     if (lane < 147 - 128) xc[lane + 128] = q;
     syy0_coarse = lane_bcast(q, 19);
   }
-  __syncthreads();
+  RN_WSYNC();
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
-  find_best_pitch(xc, y4, 240, 147, syy0_coarse, scr + SCR_SYY, bp0, bp1, lane);
+  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
+  fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
+  if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
+  WG_SYNC();
+  if (wave == 0) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
+    const int gi = lane < SPW ? lane : 0;
+    fbp_sweep(arenas[gi].a + SCR_SYY, 147, mailbox[gi * K1_MAIL + MAIL_SYY0C], lane < SPW);
+  }
+  WG_SYNC();
+  best_pitch_select(xc, scr + SCR_SYY, 147, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
   if (dbg) {
     for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
   }
-  __syncthreads();
+  RN_WSYNC();
   for (int i = lane; i < 294; i += WAVE) xc[i] = 0;
-  __syncthreads();
-  float xx, syy0_fine;
-  {  // lanes 0..9: the fine lags; lane 10: xx = <x, x> of remove_doubling; lane 11: 1 + sum x_lp[j]^2 (fine Syy start)
-    int c = (lane < 5) ? (2 * bp0 - 2 + lane) : (2 * bp1 - 2 + (lane - 5));
-    const bool lag = lane < 10 && c >= 0 && c < 294;
-    float sum = 0;
-    if (lag || lane == 10 || lane == 11)
-      sum = chain_dot8(lane == 11 ? xlp : xlp + 384, lag ? xlp + c : (lane == 11 ? xlp : xlp + 384), 480,
-                       lane == 11 ? 1.f : 0.f);
-    if (lag) xc[c] = (-1 > sum) ? -1 : sum;
-    xx = lane_bcast(sum, 10);
-    syy0_fine = lane_bcast(sum, 11);
+  // operands of the running energies of the fine search and of remove_doubling (y4 and the coarse energies are dead)
+  energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
+  if (lane == 0) {
+    mail[MAIL_BP0] = __int_as_float(bp0);
+    mail[MAIL_BP1] = __int_as_float(bp1);
   }
-  __syncthreads();
-  CLK_TAP(6);  // fine xcorr (+ the two start energies)
-  // running energies of the fine search and of remove_doubling, one shared sweep (y4 is dead)
-  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
-  energy_sweeps(xlp, rsq, Dsyy, scr + SCR_ZERO, syy0_fine, xx, lane);
+  WG_SYNC();
+  if (wave == 0) {
+    // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
+    // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch
+    {
+      const int gq = lane / 12, r = lane - 12 * gq;
+      const bool on = gq < SPW;
+      const int gi = on ? gq : 0;
+      float *xlp_g = arenas[gi].a + SCR_XLP, *xc_g = arenas[gi].a + SCR_XC, *mail_g = mailbox + gi * K1_MAIL;
+      const int b0 = __float_as_int(mail_g[MAIL_BP0]), b1 = __float_as_int(mail_g[MAIL_BP1]);
+      const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
+      const bool lag = on && r < 10 && c >= 0 && c < 294;
+      float sum = 0;
+      if (lag || (on && r >= 10))
+        sum = chain_dot8(r == 11 ? xlp_g : xlp_g + 384, lag ? xlp_g + c : (r == 11 ? xlp_g : xlp_g + 384), 480,
+                         r == 11 ? 1.f : 0.f);
+      if (lag) xc_g[c] = (-1 > sum) ? -1 : sum;
+      if (on && r == 10) mail_g[MAIL_XX] = sum;
+      if (on && r == 11) mail_g[MAIL_SYY0F] = sum;
+    }
+    RN_WSYNC();
+    CLK_TAP(6);  // fine xcorr (+ the two start energies) of the whole workgroup (wave 0's view)
+    // narrow phase 3: two lanes per stream -- the fine running energy and yy_lookup
+    {
+      const int gq = lane >> 1, role = lane & 1;
+      const bool on = gq < SPW;
+      const int gi = on ? gq : 0;
+      float *a = arenas[gi].a;
+      const float *mail_g = mailbox + gi * K1_MAIL;
+      energy_sweeps_run(a + SCR_SQ, a + SCR_D, a + SCR_ZERO, mail_g[MAIL_SYY0F], mail_g[MAIL_XX], role, on);
+    }
+    CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps of the whole workgroup (wave 0's view)
+  }
+  WG_SYNC();
+  const float xx = mail[MAIL_XX];
+  energy_sweeps_clamp(rsq, lane);
+  RN_WSYNC();
   const float *yyl = rsq + 479;  // yy_lookup[i], i = 0..384
-  CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps
   best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch selection
   int offset = 0;
@@ -755,7 +698,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const float prev_gain = g.last_gain[s];
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
-    __syncthreads();  // the fine xcorr is dead from here on; its area becomes the dots
+    RN_WSYNC();  // the fine xcorr is dead from here on; its area becomes the dots
     // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
     // independent serial sum, so computing it speculatively changes no bit):
     //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
@@ -779,7 +722,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       }
       if (off >= 0) dots[lane] = chain_dot8(x, x - off, N);
     }
-    __syncthreads();
+    RN_WSYNC();
     float xy = dots[1];
     CLK_TAP(8);  // 59 candidate dot products of remove_doubling
     float yy = yyl[T0];
@@ -837,9 +780,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     pitch_index = 2 * T + off2;
     if (pitch_index < minperiod0) pitch_index = minperiod0;
     pgain = pg;
-    __syncthreads();
+    RN_WSYNC();
   }
-  if (lane == 0) {
+  if (lane == 0 && wr) {
     g.last_period[s] = pitch_index;
     g.last_gain[s] = pgain;
     g.pitch[s] = pitch_index;
@@ -847,40 +790,48 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 
   CLK_TAP(10);  // doubling decisions + 3 final dots
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
-#pragma unroll 5
-  for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
-    const int i = lane + WAVE * t;
-    float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-    float v = PB(RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index + i) * w;
-    F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
-  }
-  {
-    // a second, opaque copy of the pointer: otherwise the per-lane twiddles of the first FFT are kept alive
-    // (and spilled to scratch) across the whole pitch stage instead of being re-read from L1/L2
-    const cpx *tw2 = tw;
-    asm volatile("" : "+s"(tw2));
-    fft960_lds(F, tw2, lane);
-  }
-  float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
-  for (int i = lane; i < RN_FREQ_SIZE; i += WAVE) {
-    cpx v = F[FPAD(i)];
-    gP[2 * i] = v.r;
-    gP[2 * i + 1] = v.i;
-  }
   float dctc[RN_NB_BANDS];  // this lane's DCT column, requested now, consumed after the band energies
+  {
+    float pr[15], pi[15], xr[8], xi[8];
+    // opaque copies of the table pointers: otherwise the window values, twiddles and lane-derived indices the first
+    // transform used are kept alive (and spilled to scratch) across the whole pitch stage instead of being re-read from L1/L2
+    const float *hw2 = tb.half_window;
+    const float2 *ftw2 = ftw;
+    int lane2 = lane;
+    asm volatile("" : "+s"(hw2), "+s"(ftw2), "+v"(lane2));
+    window_to_regs(pr, pi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index, hw2);
+    // X is read back from HBM/L2 (this wave wrote it; its stores are long complete), in the lane-owns-bins layout
 #pragma unroll
-  for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
-  band_accumulate<true, true>(Ep, F, F, Qs, sums, tb, lane);
-  // X is read back from HBM/L2 (this block wrote it; the barriers since then make it visible)
-  band_accumulate<false, true>(Exp, reinterpret_cast<const cpx *>(gX), F, Qs, sums, tb, lane);
+    for (int j = 0; j < 8; j++) {
+      const int bin = WAVE * j + pos;
+      const float2 v = reinterpret_cast<const float2 *>(gX)[bin < RN_FREQ_SIZE ? bin : 0];
+      xr[j] = v.x;
+      xi[j] = v.y;
+    }
+#pragma unroll
+    for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
+    regfft960<RN_FFT_XLANE>(pr, pi, lane2, ftw2);
+    float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int bin = WAVE * j + pos;
+      if (bin < RN_FREQ_SIZE && wr) reinterpret_cast<float2 *>(gP)[bin] = make_float2(pr[j], pi[j]);
+    }
+    band_products(Qs, pr, pi, pr, pi, tb, pos);
+    band_chain(Ep, Qs, sums, tb, lane);
+    band_products(Qs, xr, xi, pr, pi, tb, pos);
+  }
+  band_chain(Exp, Qs, sums, tb, lane);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
-    gE[lane] = Ex[lane];
-    gE[32 + lane] = Ep[lane];
-    gE[64 + lane] = Exp[lane];
+    if (wr) {
+      gE[lane] = Ex[lane];
+      gE[32 + lane] = Ep[lane];
+      gE[64 + lane] = Exp[lane];
+    }
   }
-  __syncthreads();
+  RN_WSYNC();
 
   // ---- features (src/denoise.c:378-397) ----
   float *feat = g.features + (size_t)s * 68;
@@ -889,7 +840,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     f_hi = dct_lane(Exp, dctc, tb);
     Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
   }
-  __syncthreads();
+  RN_WSYNC();
   // log-energy follower + total energy: 32 serial steps, evaluated uniformly.  The reference forms
   // follow-1.5 in double and rounds the selected maximum to float (src/denoise.c:381-386); follow-1.5 is
   // exact in double, rounding is monotonic and the other operands are floats, so
@@ -909,12 +860,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       if (lane == 0) Ly[i] = ly;
     }
   }
-  __syncthreads();
+  RN_WSYNC();
   // inference: silent frames zero the features and skip the network (src/denoise.c:389-393);
   // TRAINING build: features are always produced and "silence" means E < 0.1 (:389,:397)
   const int silence = TRAIN ? (((double)E < 0.1) ? 1 : 0) : (((double)E < 0.04) ? 1 : 0);
   const bool zero = !TRAIN && silence;
-  if (lane < RN_NB_BANDS) {
+  if (lane < RN_NB_BANDS && wr) {
     float f_lo = dct_lane(Ly, dctc, tb);
     if (lane == 0) f_lo -= 12;
     if (lane == 1) f_lo -= 4;
@@ -925,7 +876,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       tr.rec[(size_t)s * 98 + RN_NB_BANDS + lane] = f_hi;
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && wr) {
     const float fp = (float)(.01 * (double)(pitch_index - 300));
     feat[2 * RN_NB_BANDS] = zero ? 0.f : fp;
     if (TRAIN) tr.rec[(size_t)s * 98 + 2 * RN_NB_BANDS] = fp;
@@ -933,20 +884,33 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   if (TRAIN) {
     // rnn_frame_analysis of the CLEAN frame (src/dump_features.c:468) and the band-gain targets (:472-478)
-    __syncthreads();
+    RN_WSYNC();
     float *cm = tr.clean_mem + (size_t)s * RN_FRAME_SIZE;
     const float *cx = tr.clean + (size_t)s * RN_FRAME_SIZE;
-    for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
-      float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-      float v = (i < RN_FRAME_SIZE ? cm[i] : cx[i - RN_FRAME_SIZE]) * w;
-      F[bitrev960(i)] = {0.0010416667f * v, 0.0010416667f * 0.f};
-    }
-    fft960_lds(F, tw, lane);
-    for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) cm[i] = cx[i];
-    for (int i = tr.lowpass[s] + lane; i < RN_FREQ_SIZE; i += WAVE) F[FPAD(i)] = {0.f, 0.f};
-    __syncthreads();
     float *Ey = Ep;  // Ep already went to HBM
-    band_accumulate<true, true>(Ey, F, F, Qs, sums, tb, lane);
+    {
+      float yr[15], yi[15];
+      for (int i = lane; i < RN_WINDOW_SIZE; i += WAVE) {
+        const float w = tb.half_window[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
+        S[i] = (i < RN_FRAME_SIZE ? cm[i] : cx[i - RN_FRAME_SIZE]) * w;
+      }
+      RN_WSYNC();
+      const float *run = S + 15 * fft_lam(lane);
+#pragma unroll
+      for (int b = 0; b < 15; b++) {
+        yr[b] = 0.0010416667f * run[fft_c(b)];
+        yi[b] = 0.0010416667f * 0.f;
+      }
+      RN_WSYNC();
+      regfft960<RN_FFT_XLANE>(yr, yi, lane, ftw);
+      for (int i = lane; i < RN_FRAME_SIZE; i += WAVE) cm[i] = cx[i];
+      const int lp = tr.lowpass[s];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (WAVE * j + pos >= lp) yr[j] = yi[j] = 0.f;
+      band_products(Qs, yr, yi, yr, yi, tb, pos);
+    }
+    band_chain(Ey, Qs, sums, tb, lane);
     if (lane < RN_NB_BANDS) {
       float gt = (float)sqrt(((double)Ey[lane] + 1e-3) / ((double)Ex[lane] + 1e-3));
       if (gt > 1) gt = 1;
@@ -962,92 +926,66 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 #undef PB
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
+// (4 waves per SIMD is what the LDS allows: 16 arenas of 10 KB per CU; without the cap the allocator spreads to 154 VGPRs)
+extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
-  analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
+  analysis_body<false, K1_SPW>(g, tb, slot, parity, RnTrainArgs{});
 }
-// The same kernel held to 80 VGPRs (a few registers spilled, ~1 % slower by itself).  While a 16-stream tile of
-// the network kernel is resident on a CU (2 waves x 120 VGPRs per SIMD), only 272 VGPRs per SIMD are left: two
-// waves of the 104-register build, three of this one -- 12 analysis waves beside the tile instead of 8, which is
-// also what the LDS allows.  Measured (same box): +7.7 % at 4096 streams, +2.3 % at 8192, 0 at 6144, +1.5 % at 16,384,
-// -2.5 % at <= 2048 (too few waves for it to matter), -0.6 % at 32,768 and 65,536 (no overlap left)
-// => used from 3072 to 24575 streams.
-extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
-rn_analysis_lean_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
-  analysis_body<false>(g, tb, slot, parity, RnTrainArgs{});
+// One stream per workgroup: batches that fit in one round of resident waves (<= 16 per CU) are bound by a wave's latency,
+// not by instruction issue, and there the narrow phases are better run by every wave for itself.  Measured on MI355X
+// (pipelined bench, M frames/s, 1 vs K1_SPW streams per workgroup): 2048 streams 13.9 / 14.0, 4096: 20.0 / 18.3,
+// 8192: 17.7 / 19.6, 16,384: 19.0 / 22.1.  (Round 1's 80-VGPR "lean" build no longer pays at any size and is gone.)
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
+rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
+  analysis_body<false, 1>(g, tb, slot, parity, RnTrainArgs{});
 }
 
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnTrainArgs tr) {
-  analysis_body<true>(g, tb, slot, parity, tr);
+  analysis_body<true, 1>(g, tb, slot, parity, tr);
 }
 
 
 struct SynthLds {
-  cpx F[RN_FFT_PADDED];  // inverse-FFT work area (padded layout); band products before that
+  cpx S[RN_WINDOW_SIZE];  // Hermitian-extended spectrum in natural order (staging for the transform); band products before that
   float misc[192];
 };
-
-// the second half of band_accumulate for callers that formed the 800 products themselves
-__device__ void band_chain_finish(float *bandE, const float *Q, float *sums, int lane) {
-  __syncthreads();
-  {
-    const int k = lane < RN_NB_BANDS + 2 ? lane : 0;
-    const int lo = k ? c_eband[k - 1] : 0;
-    const int len = lane < RN_NB_BANDS + 2 ? (k <= RN_NB_BANDS ? c_eband[k + 1] : 400) - lo : 0;
-    const float *q = Q + lo + c_eband[k];
-    float s = 0;
-#pragma unroll 4
-    for (int t = 0; t < 84; t++) {
-      const float v = q[t];
-      s += (t < len) ? v : 0.f;
-    }
-    if (lane < RN_NB_BANDS + 2) sums[lane] = s;
-  }
-  __syncthreads();
-  if (lane < RN_NB_BANDS) {
-    float v = sums[lane + 1];
-    if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
-    if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
-    bandE[lane] = v;
-  }
-  __syncthreads();
-}
 
 // ---------------------------------------------------------------------------------------------
 // K3: rnn_pitch_filter + gain smoothing/interpolation + frame_synthesis
 // (src/denoise.c:474-496, 421-455, 140-154, 400-407, 200-217)
-// Lane l owns bins l, l+64, ..., l+448 (and bin 480 for lane 32) in registers for the whole
-// kernel; every HBM operand is requested before the first dependent instruction, so the wave
-// pays one memory round trip instead of one per stage.  8.4 KB of LDS per wave.
+// Lane l owns bins p, p+64, ..., p+448 (p = fft_pos(l); bin 480 is the j = 7 bin of the lane with p = 32) in registers
+// through the band stages; every HBM operand is requested before the first dependent instruction, so the wave pays one
+// memory round trip instead of one per stage.  The inverse transform is the register-resident FFT of fft_reg.h: the
+// Hermitian-extended spectrum passes once through LDS (natural order in, 15 consecutive bins out per lane) and the time
+// samples come out in registers, lane l holding work-area positions 64*blk + p.  7.8 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity, int prev) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
+  const int s = blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
   const float *cE = g.spec_E[parity] + (size_t)s * 96;
   float *r = L.misc + 0, *gsm = L.misc + 32, *newE = L.misc + 64, *norm = L.misc + 96, *sums = L.misc + 128;
-  float *Q = reinterpret_cast<float *>(L.F);
+  float *Q = reinterpret_cast<float *>(L.S);
   const int silence = g.silence[s];
-  constexpr int NBIN = 8;  // bins lane + 64*j; the 481st bin (480) is lane 32's j = 7
+  constexpr int NBIN = 8;  // bins pos + 64*j
 
   // ---- every HBM operand up front ----
   float2 X[NBIN], P[NBIN];
   float frac[NBIN];
-  int band[NBIN];
+  uint32_t bq[NBIN];  // RnTablesDev::band_q: slot of the (1-frac) term | slot of the frac term << 10 | band << 20
 #pragma unroll
   for (int j = 0; j < NBIN; j++) {
-    const int bin = lane + WAVE * j;
+    const int bin = pos + WAVE * j;
     const bool ok = bin < RN_FREQ_SIZE;
     X[j] = ok ? dX[bin] : make_float2(0.f, 0.f);
     P[j] = (ok && !silence) ? dP[bin] : make_float2(0.f, 0.f);
-    band[j] = (bin < 400) ? tb.band_of_bin[bin] : 0;
+    bq[j] = (bin < 400) ? tb.band_q[bin] : 0u;
     frac[j] = (bin < 400) ? tb.band_frac[bin] : 0.f;
   }
   float e_ex = 0, e_ep = 0, e_exp = 0, c_ex = 0, gi = 0, lastg = 0;
@@ -1056,23 +994,27 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     gi = g.gains[(size_t)s * RN_NB_BANDS + lane];
     lastg = g.lastg[(size_t)s * RN_NB_BANDS + lane];
   }
+  // After the transform this lane holds y[p], p = 64*blk + pos, blk = 0..14; time sample n = (960 - p) % 960
+  // (src/denoise.c:213-216).  n < 480: out[n] = 960*y*w[n] + synthesis_mem[n];  n >= 480: synthesis_mem[n - 480] =
+  // 960*y*w[959 - n] = 960*y*w[p - 1]  (src/denoise.c:400-407).  Operands of both are requested now.
   float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
-  float smv[8], wlo[8], whi[8];
+  float smv[15], wv[15];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int i = lane + WAVE * j;
-    const bool ok = i < RN_FRAME_SIZE;
-    smv[j] = ok ? sm[i] : 0.f;
-    wlo[j] = ok ? tb.half_window[i] : 0.f;
-    whi[j] = ok ? tb.half_window[RN_FRAME_SIZE - 1 - i] : 0.f;
+  for (int b = 0; b < 15; b++) {
+    const int p = WAVE * b + pos;
+    const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
+    const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
+    wv[b] = tb.half_window[n];
+    smv[b] = lo ? sm[n] : 0.f;
   }
 
 // src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
+#define BAND(j) ((int)(bq[j] >> 20))
 #define INTERP(vec, j)                                                                                      \
-  ((lane + WAVE * (j)) >= 400 ? 0.f                                                                         \
-   : band[j] == 0 ? (vec)[0]                                                                                \
-   : band[j] == RN_NB_BANDS ? (vec)[RN_NB_BANDS - 1]                                                        \
-                            : (1 - frac[j]) * (vec)[band[j] - 1] + frac[j] * (vec)[band[j]])
+  ((pos + WAVE * (j)) >= 400 ? 0.f                                                                          \
+   : BAND(j) == 0 ? (vec)[0]                                                                                \
+   : BAND(j) == RN_NB_BANDS ? (vec)[RN_NB_BANDS - 1]                                                        \
+                            : (1 - frac[j]) * (vec)[BAND(j) - 1] + frac[j] * (vec)[BAND(j)])
 
   if (!silence) {
     if (lane < RN_NB_BANDS) {  // src/denoise.c:429-440
@@ -1085,21 +1027,21 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       rv = (float)((double)rv * sqrt((double)e_ex / (1e-8 + (double)e_ep)));
       r[lane] = rv;
     }
-    __syncthreads();
+    RN_WSYNC();
 #pragma unroll
     for (int j = 0; j < NBIN; j++) {  // :441-445, then the products of compute_band_energy (:446)
-      const int bin = lane + WAVE * j;
+      const int bin = pos + WAVE * j;
       const float rf = INTERP(r, j);
       X[j].x += rf * P[j].x;
       X[j].y += rf * P[j].y;
       if (bin < 400) {
         float tmp = X[j].x * X[j].x;
         tmp += X[j].y * X[j].y;
-        Q[c_eband[band[j] + 1] + bin] = frac[j] * tmp;
-        Q[c_eband[band[j]] + bin] = (1 - frac[j]) * tmp;
+        Q[(bq[j] >> 10) & 0x3ff] = frac[j] * tmp;
+        Q[bq[j] & 0x3ff] = (1 - frac[j]) * tmp;
       }
     }
-    band_chain_finish(newE, Q, sums, lane);
+    band_chain(newE, Q, sums, tb, lane);
     if (lane < RN_NB_BANDS) {
       norm[lane] = (float)sqrt((double)e_ex / (1e-8 + (double)newE[lane]));  // :447-449
       const float alpha = .6f;  // gain smoothing (src/denoise.c:479-487)
@@ -1108,7 +1050,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       g.lastg[(size_t)s * RN_NB_BANDS + lane] = (float)((1.f < q) ? 1.f : q);
       gsm[lane] = gi;
     }
-    __syncthreads();
+    RN_WSYNC();
 #pragma unroll
     for (int j = 0; j < NBIN; j++) {  // :450-454 then :488-493
       const float nf = INTERP(norm, j), gf = INTERP(gsm, j);
@@ -1117,35 +1059,79 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       X[j].x *= gf;
       X[j].y *= gf;
     }
-    __syncthreads();
+    RN_WSYNC();
   }
 #undef INTERP
-  // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT
+#undef BAND
+  // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT.  Natural order into LDS ...
 #pragma unroll
   for (int j = 0; j < NBIN; j++) {
-    const int bin = lane + WAVE * j;
+    const int bin = pos + WAVE * j;
     if (bin < RN_FREQ_SIZE) {
-      L.F[bitrev960(bin)] = {0.0010416667f * X[j].x, 0.0010416667f * X[j].y};
-      if (bin > 0 && bin < RN_FREQ_SIZE - 1)
-        L.F[bitrev960(RN_WINDOW_SIZE - bin)] = {0.0010416667f * X[j].x, 0.0010416667f * (-X[j].y)};
+      L.S[bin] = {0.0010416667f * X[j].x, 0.0010416667f * X[j].y};
+      if (bin > 0 && bin < RN_FREQ_SIZE - 1) L.S[RN_WINDOW_SIZE - bin] = {0.0010416667f * X[j].x, 0.0010416667f * (-X[j].y)};
     }
   }
-  fft960_lds(L.F, tw, lane);
-  // window + overlap-add (src/denoise.c:400-407)
+  RN_WSYNC();
+  // ... and this lane's 15 consecutive bins out of it (fft_reg.h "Input")
+  float yr[15], yi[15];
+  {
+    const cpx *run = L.S + 15 * fft_lam(lane);
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+      const cpx v = run[fft_c(b)];
+      yr[b] = v.r;
+      yi[b] = v.i;
+    }
+  }
+  regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));
+  // window + overlap-add (src/denoise.c:400-407), straight from the registers
   float *o = out + (size_t)s * RN_FRAME_SIZE;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int i = lane + WAVE * j;
-    if (i < RN_FRAME_SIZE) {
-      const int ilo = (RN_WINDOW_SIZE - i) % RN_WINDOW_SIZE, ihi = RN_FRAME_SIZE - i;
-      float lo = (float)RN_WINDOW_SIZE * L.F[FPAD(ilo)].r;  // x[i]
-      float hi = (float)RN_WINDOW_SIZE * L.F[FPAD(ihi)].r;  // x[480+i], window index 479-i
-      lo *= wlo[j];
-      hi *= whi[j];
-      o[i] = lo + smv[j];
-      sm[i] = hi;
-    }
+  for (int b = 0; b < 15; b++) {
+    const int p = WAVE * b + pos;
+    const bool lo = p == 0 || p > RN_FRAME_SIZE;
+    const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
+    float v = (float)RN_WINDOW_SIZE * yr[b];
+    v *= wv[b];
+    if (lo) o[n] = v + smv[b];
+    else sm[RN_FRAME_SIZE - p] = v;
   }
+}
+
+// measurement twin of fft_probe.hip for the LDS work-area FFT above (same feedback protocol, 10 KB of LDS per wave like K1)
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_fft_probe_lds_kernel(const float *__restrict__ in, float *__restrict__ out, unsigned long long *__restrict__ clocks, int reps,
+                        RnTablesDev tb) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cpx *F = reinterpret_cast<cpx *>(smem_raw);
+  const int lane = threadIdx.x, w = blockIdx.x;
+  const float2 *x = reinterpret_cast<const float2 *>(in) + (size_t)w * 960;
+  float2 *y = reinterpret_cast<float2 *>(out) + (size_t)w * 960;
+  const cpx *tw = reinterpret_cast<const cpx *>(tb.twiddles);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = lane; i < 960; i += WAVE) {
+    const float2 v = x[i];
+    F[bitrev960(i)] = {0.0010416667f * v.x, 0.0010416667f * v.y};
+  }
+  for (int r = 0; r < reps; r++) {
+    if (r) {  // timing passes: the (rescaled) spectrum is the next input, in place
+      RN_WSYNC();
+      for (int i = lane; i < 960; i += WAVE) {
+        cpx v = F[FPAD(i)];
+        F[FPAD(i)] = {0.03125f * v.r, 0.03125f * v.i};
+      }
+    }
+    fft960_lds(F, tw, lane);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  for (int i = lane; i < 960; i += WAVE) y[i] = make_float2(F[FPAD(i)].r, F[FPAD(i)].i);
+  if (lane == 0 && clocks) clocks[w] = t1 - t0;
+}
+extern "C" hipError_t rn_launch_fft_probe_lds(const float *in, float *out, unsigned long long *clocks, int n, int reps,
+                                              const RnTablesDev *tb, hipStream_t st) {
+  hipLaunchKernelGGL(rn_fft_probe_lds_kernel, dim3(n), dim3(WAVE), 10240, st, in, out, clocks, reps, *tb);
+  return hipGetLastError();
 }
 
 // test tap: the log-energy expression of the feature stage (src/denoise.c:383) on arbitrary inputs, so that a sweep can
@@ -1160,26 +1146,30 @@ extern "C" hipError_t rn_launch_log_energy(const float *ex, float *out, int n, h
 }
 
 // host-visible launch helpers -----------------------------------------------------------------
-// K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
-  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, in, slot, 1);
-  return hipGetLastError();
-}
+// (K0 lives in hp_kernel.hip; K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream)
+extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st);  // hp_kernel.hip
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev *tb, int slot, int parity, hipStream_t st,
                                          hipEvent_t e0, hipEvent_t e1) {
-  static const int force = [] { const char *e = getenv("RNNOISE_AMD_K1_LEAN"); return e ? atoi(e) : -1; }();  // 0 / 1: A/B runs
-  const bool lean = force >= 0 ? force != 0 : (g->n_streams >= RN_K1_LEAN_MIN_STREAMS && g->n_streams < RN_K1_LEAN_MAX_STREAMS);
-  if (lean)
-    RN_LAUNCH(rn_analysis_lean_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, e0, e1, *g, *tb, slot, parity);
-  else
-    RN_LAUNCH(rn_analysis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, e0, e1, *g, *tb, slot, parity);
+  // A/B runs only: RNNOISE_AMD_K1_SPW=1 / 4 forces one / K1_SPW streams per workgroup; RNNOISE_AMD_K1_LDS -> a larger
+  // LDS request per wave lowers the waves per CU (occupancy experiments)
+  static const int spw_force = [] { const char *e = getenv("RNNOISE_AMD_K1_SPW"); return e ? atoi(e) : 0; }();
+  static const size_t lds1 = [] { const char *e = getenv("RNNOISE_AMD_K1_LDS"); return e ? (size_t)atoi(e) : sizeof(AnalysisLds); }();
+  const int n = g->n_streams;
+  const bool single = spw_force == 1 || (spw_force == 0 && n < RN_K1_MULTI_MIN_STREAMS);
+  if (single) {
+    RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1 + K1_MAIL * 4, st, e0, e1, *g, *tb, slot, parity);
+  } else {
+    const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1 + K1_SPW * K1_MAIL * 4, st, e0, e1, *g, *tb, slot, parity);
+  }
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTablesDev *tb, const float *noisy, int slot,
                                                int parity, const RnTrainArgs *tr, hipStream_t st) {
-  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, noisy, slot, 0);
-  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, slot,
-                     parity, *tr);
+  hipError_t e = rn_launch_hp_passthrough(g, noisy, slot, st);  // training frames arrive filtered: K0 without the biquad
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds) + K1_MAIL * 4, st, *g, *tb,
+                     slot, parity, *tr);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int cur, int prev,

@@ -1,0 +1,181 @@
+// hp_kernel.hip -- K0: the per-stream serial front end (high-pass, pitch-buffer decimation, 5-lag autocorrelation,
+// Levinson), transposed to lane = stream.  Kept in its own translation unit because it is compiled WITH the SLP
+// vectoriser (its unrolled float4 blocks pack well: ~9 % fewer instructions), whereas dsp_kernels.hip is compiled with
+// -fno-slp-vectorize (register-resident FFT: packed math there costs 40 VGPRs and the DPP folding of the exchanges).
+// Numerics contract as in dsp_kernels.hip: -ffp-contract=off, reference order of every float sum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rn_dev.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// K0: rnn_biquad (src/denoise.c:409-419, coefficients :469-470), transposed: lane = stream.
+// The recurrence is strictly serial per stream (every step rounds its state to float), so the
+// wave-per-frame kernel would idle 63 of 64 lanes for 480 steps; here 64 streams advance in
+// lock-step instead.  Output goes straight into the stream's pitch ring (slot `slot`).
+// a0*yi and a1*yi are products of two 24-bit significands, exact in double, so
+// fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp) {
+  const int s = blockIdx.x * WAVE + threadIdx.x;
+  if (s >= g.n_streams) return;
+  const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
+  const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
+  float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
+  const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
+  float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
+  // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
+  // filtered: with one wave per SIMD nothing else hides the HBM round trip
+  constexpr int BLK = 8;  // float4 per block
+  float4 cur[BLK], nxt[BLK];
+#pragma unroll
+  for (int j = 0; j < BLK; j++) nxt[j] = x[j];
+  for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
+#pragma unroll
+    for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+    if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) nxt[j] = x[(blk + 1) * BLK + j];
+    }
+#define HP_STEP(xi, yo)                                              \
+    {                                                                \
+      const float yi = (xi) + m0;                                    \
+      const double xd = (double)(xi), yd = (double)yi;               \
+      m0 = (float)((double)m1 + fma(na0, yd, b0d * xd));             \
+      m1 = (float)fma(na1, yd, xd);                                  \
+      (yo) = yi;                                                     \
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      const float4 v = cur[j];
+      float4 o;
+      if (apply_hp) {
+        HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+      } else {
+        o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
+      }
+      y[blk * BLK + j] = o;
+    }
+#undef HP_STEP
+  }
+  if (apply_hp) {
+    g.mem_hp[2 * s] = m0;
+    g.mem_hp[2 * s + 1] = m1;
+  }
+
+  // ---- rnn_pitch_downsample's serial half (src/pitch.c:146-214): 2x decimation, 5-lag autocorrelation
+  // (src/celt_lpc.c:92-174), lag window, order-4 Levinson (src/celt_lpc.c:38-89) -> the 5 FIR taps.
+  // In the wave-per-frame kernel these 5 chains of 864 steps used 5 lanes of 64; here every lane
+  // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
+  // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
+  // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
+  {
+    const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
+    const int ring0 = RN_RING0(slot);
+    // pitch_buf in blocks of 32 floats (8 float4); ring0 and the ring size are multiples of 32, so a block never
+    // straddles the wrap; the next block is requested before this one is consumed
+    auto block = [&](int b, float4 (&dst)[BLK]) {
+      int p = ring0 + 32 * b;
+      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
+      const float4 *src = reinterpret_cast<const float4 *>(ring + p);
+#pragma unroll
+      for (int j = 0; j < BLK; j++) dst[j] = src[j];
+    };
+    float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
+    float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
+    float prev = 0;                          // pitch_buf[4c-1]
+    block(0, nxt);
+    for (int b = 0; b < RN_PITCH_BUF_SIZE / 32; b++) {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+      if (b + 1 < RN_PITCH_BUF_SIZE / 32) block(b + 1, nxt);
+#pragma unroll
+      for (int j = 0; j < BLK; j++) {
+        const int c = b * BLK + j;
+        const float4 v = cur[j];
+        float xl[2];
+        xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
+        xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
+        prev = v.w;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int t = 2 * c + h;
+          const float x0 = xl[h];
+          if (t < 860) {
+            ac[0] = ac[0] + x0 * x0;
+            ac[1] = ac[1] + w1 * x0;
+            ac[2] = ac[2] + w2 * x0;
+            ac[3] = ac[3] + w3 * x0;
+            ac[4] = ac[4] + w4 * x0;
+          } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
+            const int e = t - 860;
+            d[0] = d[0] + x0 * x0;
+            if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
+            if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
+            if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
+            ac[4] = ac[4] + w4 * x0;
+          }
+          w4 = w3; w3 = w2; w2 = w1; w1 = x0;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
+    ac[0] *= 1.0001f;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+    float lpc[4] = {0, 0, 0, 0};
+    if (ac[0] != 0) {
+      float error = ac[0];
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (!done) {
+          float rr = 0;
+#pragma unroll
+          for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+          rr += ac[i + 1];
+          const float r = -rr / error;
+          lpc[i] = r;
+#pragma unroll
+          for (int j = 0; j < (i + 1) >> 1; j++) {
+            const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+            lpc[j] = t1 + r * t2;
+            lpc[i - 1 - j] = t2 + r * t1;
+          }
+          error = error - (r * r) * error;
+          if (error < .001f * ac[0]) done = true;  // `break` (celt_lpc.c:81-82)
+        }
+      }
+    }
+    float tmp = 1.f;
+    const float c1 = .8f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      tmp = .9f * tmp;
+      lpc[i] = lpc[i] * tmp;
+    }
+    float *o = g.lpc2 + ((size_t)slot * g.n_streams + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
+    o[0] = lpc[0] + .8f;
+    o[1] = lpc[1] + c1 * lpc[0];
+    o[2] = lpc[2] + c1 * lpc[1];
+    o[3] = lpc[3] + c1 * lpc[2];
+    o[4] = c1 * lpc[3];
+    if (g.debug) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
+    }
+  }
+}
+
+
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
+  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, in, slot, 1);
+  return hipGetLastError();
+}
+extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot, 0);
+  return hipGetLastError();
+}

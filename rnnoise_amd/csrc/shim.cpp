@@ -30,6 +30,8 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, 
                                         hipEvent_t);
 extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
+extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);
 
 
 // Every entry point works on the batch's device and leaves the calling thread's current device as it found it
@@ -339,7 +341,44 @@ int tables_for_device(int device, RnTablesDev &out) {
       band_of[kEband[b] + j] = (uint8_t)b;
     }
   }
+  // per-lane twiddles of the register-resident FFT (fft_reg.h): lane l ends a radix-4 stage holding the position whose
+  // digit is the bit-reversed lane digit, so every stage's twiddle index is tabulated with the true position
+  std::vector<float> ftw(16 * 64 * 2);
+  for (int l = 0; l < 64; l++) {
+    auto sig = [](int d) { return ((d & 1) << 1) | (d >> 1); };
+    const int p4 = sig(l & 3), p16 = p4 + 4 * sig((l >> 2) & 3), q = p16 + 16 * sig(l >> 4);
+    auto put = [&](int row, int e) {
+      ftw[(row * 64 + l) * 2] = tw[2 * (e % RN_WINDOW_SIZE)];
+      ftw[(row * 64 + l) * 2 + 1] = tw[2 * (e % RN_WINDOW_SIZE) + 1];
+    };
+    put(0, 60 * p4 * ((l >> 2) & 3));   // m = 4 stage,  fstride 60 (src/kiss_fft.c:141-165)
+    put(1, 15 * p16 * (l >> 4));        // m = 16 stage, fstride 15
+    put(2, 5 * q);                      // radix 3, m = 64, fstride 5 (:201-225)
+    put(3, 10 * q);
+    for (int t = 0; t < 3; t++)         // radix 5, m = 192, fstride 1 (:269-302), j = 64 t + q
+      for (int mlt = 1; mlt <= 4; mlt++) put(4 + 4 * t + (mlt - 1), mlt * (64 * t + q));
+  }
+  // band-sum layout (dsp_kernels.hip: band_products / band_chain): accumulator k's terms -- band k-1's `frac` parts, then
+  // band k's `1-frac` parts, in bin order (src/denoise.c:90-113) -- sit contiguously from a 16-byte aligned start, so the
+  // serial sum reads them four at a time.  band_q[bin] = address of the (1-frac) term | address of the frac term << 10 |
+  // band << 20;  band_chain[k] = start | length << 16.
+  std::vector<uint32_t> band_q(400), band_chain(RN_NB_BANDS + 2);
+  {
+    int start[RN_NB_BANDS + 2], lo[RN_NB_BANDS + 2], pos = 0;
+    for (int k = 0; k < RN_NB_BANDS + 2; k++) {
+      lo[k] = k ? kEband[k - 1] : 0;
+      const int len = (k <= RN_NB_BANDS ? kEband[k + 1] : 400) - lo[k];
+      start[k] = pos;
+      band_chain[k] = (uint32_t)pos | ((uint32_t)len << 16);
+      pos += (len + 3) & ~3;
+    }
+    for (int b = 0; b <= RN_NB_BANDS; b++)
+      for (int bin = kEband[b]; bin < kEband[b + 1]; bin++)
+        band_q[bin] = (uint32_t)(start[b] + bin - lo[b]) | ((uint32_t)(start[b + 1] + bin - lo[b + 1]) << 10) | ((uint32_t)b << 20);
+  }
   Staging st;
+  size_t o_ftw = st.add(ftw.data(), 4 * ftw.size());
+  size_t o_bq = st.add(band_q.data(), 4 * band_q.size()), o_bc = st.add(band_chain.data(), 4 * band_chain.size());
   size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
          o_t = st.add(tw.data(), 4 * tw.size()), o_f = st.add(frac.data(), 4 * frac.size()),
          o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(RN_RCP_LUT_X86, sizeof RN_RCP_LUT_X86),
@@ -357,6 +396,9 @@ int tables_for_device(int device, RnTablesDev &out) {
   t.dev.band_of_bin = base + o_b;
   t.dev.bitrev = reinterpret_cast<const uint16_t *>(base + o_br);
   t.dev.rcp_lut = reinterpret_cast<const uint32_t *>(base + o_r);
+  t.dev.fft_tw = reinterpret_cast<const float *>(base + o_ftw);
+  t.dev.band_q = reinterpret_cast<const uint32_t *>(base + o_bq);
+  t.dev.band_chain = reinterpret_cast<const uint32_t *>(base + o_bc);
   t.dev.dct_scale = sqrt(2. / 22);
   g_tables.push_back(t);
   out = t.dev;
@@ -932,6 +974,35 @@ extern "C" int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst) {
   }
   if (dst) D2H(dst, b->debug_buf, (size_t)b->n * RN_DBG_FLOATS);
   return 0;
+}
+
+// n independent 960-point transforms through the register-resident FFT (fft_reg.h), `reps` passes each (the spectrum is
+// fed back as the next input); variant 0 = all exchanges through ds_bpermute, 1 = the DPP / swizzle forms the kernels use.
+// in / out: [n][960][2] host floats (natural order; the 1/960 input scale of kiss_fft.c:582 is applied on the first pass);
+// clocks (optional): [n] shader clocks per wave; xlane (optional): [2][6][64] source lane delivered by each exchange
+// primitive for xor masks 1,2,4,8,16,32.  Tests and tools only.
+extern "C" int rnnoise_amd_debug_fft(int device, int variant, float *out, const float *in, int n, int reps,
+                                     unsigned long long *clocks, int *xlane) {
+  if (!out || !in || n <= 0 || reps <= 0) return -1;
+  ON_DEVICE(device);
+  RnTablesDev tb;
+  if (tables_for_device(device, tb)) return -1;
+  const size_t fb = (size_t)n * 960 * 2 * 4;
+  char *d = nullptr;
+  HIP_OK(hipMalloc((void **)&d, 2 * fb + (size_t)n * 8 + 2 * 6 * 64 * 4));
+  float *d_in = (float *)d, *d_out = (float *)(d + fb);
+  unsigned long long *d_clk = (unsigned long long *)(d + 2 * fb);
+  int *d_x = (int *)(d + 2 * fb + (size_t)n * 8);
+  int rc = -1;
+  if (hipMemcpy(d_in, in, fb, hipMemcpyHostToDevice) == hipSuccess &&
+      rn_launch_fft_probe(variant, d_in, d_out, d_clk, n, reps, &tb, nullptr) == hipSuccess &&
+      rn_launch_xlane_probe(d_x, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
+      hipMemcpy(out, d_out, fb, hipMemcpyDeviceToHost) == hipSuccess &&
+      (!clocks || hipMemcpy(clocks, d_clk, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess) &&
+      (!xlane || hipMemcpy(xlane, d_x, 2 * 6 * 64 * 4, hipMemcpyDeviceToHost) == hipSuccess))
+    rc = 0;
+  hipFree(d);
+  return rc;
 }
 
 // out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on the device (host buffers; tests only)

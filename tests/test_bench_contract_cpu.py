@@ -12,7 +12,7 @@ import bench  # noqa: E402
 
 def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
     for n in (1024, 4096, 16384, 65536, 524288 // 8):
-        for k in ("rn_hp_kernel", "rn_analysis_kernel", "rn_analysis_lean_kernel", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
+        for k in ("rn_hp_kernel", "rn_analysis_kernel", "rn_analysis_single_kernel", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
             r = bench.pmc_record(k, n)
             assert r and r["hbm_bytes_per_frame"] > 1000 and r["valu_per_wave"] > 100, (k, n, r)
     assert bench.pmc_record("rn_nn_vector_kernel", 4096) is None  # never profiled with PMC: traffic is reported as null
@@ -66,7 +66,7 @@ def test_committed_bench_lines_follow_the_contract():
         assert d["repeats"] >= 5 and d["value_min"] <= d["value"] <= d["value_max"], f
         # numerator and denominator of the roofline cover the same kernel (round-1 ADVICE): its own bytes / its own time
         r = d["roofline"]
-        kind = {"rn_hp_kernel": "highpass", "rn_analysis_kernel": "analysis", "rn_analysis_lean_kernel": "analysis",
+        kind = {"rn_hp_kernel": "highpass", "rn_analysis_kernel": "analysis", "rn_analysis_single_kernel": "analysis",
                 "rn_nn_mfma_kernel": "network", "rn_nn_vector_kernel": "network", "rn_synthesis_kernel": "synthesis"}[r["kernel"]]
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"][kind] * 1e-3) / 1e9) < 0.02 * r["achieved"]
         if d["n_gpus"] == 1 and "cpu_baseline" in d:
