@@ -559,7 +559,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
   float lpc2[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) lpc2[k] = g.lpc2[((size_t)slot * g.n_streams + s) * 8 + k];
+  for (int k = 0; k < 5; k++) lpc2[k] = g.lpc2[((size_t)slot * g.n_stride + s) * 8 + k];
   if (dbg && lane < 5) dbg[RN_DBG_LPC + lane] = lpc2[lane];
   {  // celt_fir5 in place (src/pitch.c:104-143): outputs are independent given the OLD samples
     float r[14];

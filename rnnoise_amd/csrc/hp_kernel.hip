@@ -157,7 +157,7 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
       tmp = .9f * tmp;
       lpc[i] = lpc[i] * tmp;
     }
-    float *o = g.lpc2 + ((size_t)slot * g.n_streams + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
+    float *o = g.lpc2 + ((size_t)slot * g.n_stride + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
     o[0] = lpc[0] + .8f;
     o[1] = lpc[1] + c1 * lpc[0];
     o[2] = lpc[2] + c1 * lpc[1];

@@ -122,7 +122,7 @@ rn_nn_vector_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   __syncthreads();
   // three GRUs (src/nnet.c:65-94); thread = hidden unit
   for (int k = 0; k < 3; k++) {
-    float *st = g.gru_state + ((size_t)k * g.n_streams + s) * RN_GRU;
+    float *st = g.gru_state + ((size_t)k * g.n_stride + s) * RN_GRU;
     const float *xin = L.cat + k * RN_GRU;  // conv2 out, then the previous GRU's new state
     const float h_old = st[t];
     L.cat[(k + 1) * RN_GRU + t] = h_old;

@@ -199,7 +199,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   int cur = 1;
   CLK_TAP(2);  // conv2
   for (int k = 0; k < 3; k++) {
-    float *st = g.gru_state + (size_t)k * N * RN_GRU;
+    float *st = g.gru_state + (size_t)k * g.n_stride * RN_GRU;
     for (int e = tid; e < TS * 96; e += NTHREADS) {  // quantise the old state into hq
       const int q = e / 96, c4 = (e - q * 96) << 2, s = (s0 + q < N) ? s0 + q : N - 1;
       const v4f h = *reinterpret_cast<const v4f *>(st + (size_t)s * RN_GRU + c4);
@@ -248,7 +248,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     const int ps = (s0 + pq < N) ? s0 + pq : N - 1;
     auto chunk_src = [&](int c) {                                // chunk c = inputs 128c .. 128c+127 of cat
       const int seg = c / 3, k0 = (c - 3 * seg) * CHUNK;
-      return reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * N * RN_GRU) +
+      return reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * g.n_stride * RN_GRU) +
                                            (size_t)ps * RN_GRU + k0 + pc);
     };
     constexpr int NCH = 4 * RN_GRU / CHUNK;  // 12

@@ -61,7 +61,10 @@ struct RnModelDev {
 };
 
 struct RnGroupDev {
-  int n_streams;
+  int n_streams;   // streams this launch works on (rows 0..n_streams-1 of every array below)
+  int n_stride;    // streams the arrays were laid out for: plane stride of gru_state / lpc2.  A kernel may be pointed at a
+                   // sub-range of a batch (the pooled one-stream states behind rnnoise_create): every pointer advanced by
+                   // first_stream * row length, n_streams = count, n_stride = the batch's size
   // persistent per-stream state
   float *mem_hp;       // [N][2]
   float *pitch_ring;   // [N][RN_RING_SIZE = 2880] ring of high-passed frames; pitch_buf (src/denoise.c:76) = its latest 1728 samples

@@ -10,6 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +36,8 @@ extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);
+extern "C" hipError_t rn_launch_state_gather(const RnGroupDev *, float *, int, int, hipStream_t);
+extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *, const float *, int, int, hipStream_t);
 
 
 // Every entry point works on the batch's device and leaves the calling thread's current device as it found it
@@ -416,6 +422,7 @@ struct DeviceModel {
 // =============================================================================================
 // public types
 // =============================================================================================
+struct StatePool;
 struct RNNModel {
   const void *const_blob = nullptr;  // borrowed (rnnoise_model_from_buffer)
   void *blob = nullptr;              // owned (rnnoise_model_from_file)
@@ -425,7 +432,7 @@ struct RNNModel {
   int parsed = 0;  // 0 not yet, 1 ok, -1 rejected
   HostModel host;
   std::vector<DeviceModel> dev;
-  RNNoiseBatch *scratch = nullptr;  // 1-stream batch behind rnnoise_process_frame
+  std::vector<StatePool *> pools;  // device-resident one-stream states behind rnnoise_create / rnnoise_process_frame
   const void *bytes() const { return blob ? blob : const_blob; }
 };
 
@@ -451,9 +458,16 @@ struct RNNoiseBatch {
   RnTablesDev tb{};
   float *scratch_gains = nullptr, *scratch_vad = nullptr;
   float *debug_buf = nullptr;
-  // host-buffer staging
-  float *stage_in = nullptr, *stage_out = nullptr, *stage_vad = nullptr, *stage_gains = nullptr;
-  int stage_frames = 0;
+  float *state_stage = nullptr;  // one flat state in HBM: export / import go through the gather / scatter kernels
+  // host-fed path (rnnoise_batch_process): two chunks in flight -- H2D of chunk i+1 and D2H of chunk i-1 overlap the
+  // kernels of chunk i; pinned bounce buffers are used only when the caller's memory is pageable
+  struct HostIo {
+    hipStream_t up = nullptr, run = nullptr, down = nullptr;
+    hipEvent_t up_done[2] = {}, run_done[2] = {}, down_done[2] = {};
+    float *d_in[2] = {}, *d_out[2] = {}, *d_vad[2] = {}, *d_gains[2] = {};
+    float *h_in[2] = {}, *h_out[2] = {}, *h_vad[2] = {}, *h_gains[2] = {};
+    int chunk_frames = 0;
+  } io;
   // timing
   bool timing = false;
   struct Ev { hipEvent_t a, b; int kind; };
@@ -462,13 +476,43 @@ struct RNNoiseBatch {
   long launches = 0;
 };
 
-struct DenoiseState {  // self-contained POD: no library-owned resource (SURVEY 8b "Types")
+// A pool of device-resident one-stream states of one model on one device: the arrays of a POOL_SLOTS-stream batch, of
+// which every rnnoise_create() owns one row.  The kernels are pointed at a row through a one-stream view (rn_dev.h:
+// n_stride), so a frame of a pooled state costs one 1,920-byte upload, four launches and one 1,924-byte download.
+struct StatePool {
+  static constexpr int POOL_SLOTS = 64;
+  RNNoiseBatch *batch = nullptr;   // owns the arena; never processed as a whole
+  static constexpr int FLAT_IO = RN_STATE_FLOATS + 2;           // frame offset inside a staging block (16-byte aligned)
+  static constexpr int FLAT_BLK = FLAT_IO + RN_FRAME_SIZE + 4;  // state | pad | frame (in, then out in place) | vad | pad
+  float *d_io = nullptr;           // [POOL_SLOTS][2][484]: in[480] | pad, out[480] | vad | pad
+  float *d_flat = nullptr;         // [POOL_SLOTS][FLAT_BLK] staging for self-contained states (rnnoise_init path)
+  std::mutex mu;
+  unsigned long long used = 0;     // bit per slot
+};
+
+// What a DenoiseState holds when it came from rnnoise_create(): a row of a StatePool plus the host-side frame
+// bookkeeping of that row and its own stream / pinned buffers, so that states on different threads run concurrently.
+struct PooledRef {
+  StatePool *pool;
+  int slot;
+  int parity, ring_slot;
+  long frame_no;
+  hipStream_t stream;
+  float *h_io;        // pinned [2][484]
+  std::mutex *mu;     // one frame at a time per state (the reference's states are not re-entrant either)
+};
+
+struct DenoiseState {
   uint32_t magic;
   uint32_t pad;
   RNNModel *model;
-  float state[RN_STATE_FLOATS];
+  union {
+    float state[RN_STATE_FLOATS];  // rnnoise_init() on caller memory: self-contained POD, no library-owned resource (SURVEY 8b "Types")
+    PooledRef ref;                 // rnnoise_create(): device-resident, released by rnnoise_destroy()
+  };
 };
-static const uint32_t kStateMagic = 0x524e4e41u;  // "RNNA"
+static const uint32_t kStateMagic = 0x524e4e41u;   // "RNNA": self-contained state
+static const uint32_t kPooledMagic = 0x524e4e50u;  // "RNNP": row of a StatePool
 
 namespace {
 
@@ -523,6 +567,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   uint8_t *p = base;
   size_t N = n;
   g.n_streams = n;
+  g.n_stride = n;
   g.mem_hp = carve<float>(p, 2 * N);
   g.pitch_ring = carve<float>(p, RN_RING_SIZE * N);
   g.synth_mem = carve<float>(p, RN_FRAME_SIZE * N);
@@ -549,6 +594,40 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.lpc2 = carve<float>(p, 8 * N * RN_RING_SLOTS);
   g.train_clean_mem = carve<float>(p, RN_FRAME_SIZE * N);
   return (size_t)(p - base);
+}
+
+// rows [first, first + count) of a batch as a group of their own (rn_dev.h: n_stride keeps the plane strides)
+RnGroupDev group_view(const RnGroupDev &g, int first, int count) {
+  RnGroupDev v = g;
+  const size_t f = first;
+  v.n_streams = count;
+  v.mem_hp += 2 * f;
+  v.pitch_ring += RN_RING_SIZE * f;
+  v.synth_mem += RN_FRAME_SIZE * f;
+  v.last_gain += f;
+  v.last_period += f;
+  v.lastg += RN_NB_BANDS * f;
+  v.conv1_state += 130 * f;
+  v.conv2_state += 256 * f;
+  v.gru_state += RN_GRU * f;
+  for (int k = 0; k < RN_SPEC_SLOTS; k++) {
+    v.spec_X[k] += RN_SPEC_STRIDE * f;
+    v.spec_P[k] += RN_SPEC_STRIDE * f;
+    v.spec_E[k] += 96 * f;
+  }
+  v.features += 68 * f;
+  v.silence += f;
+  v.pitch += f;
+  v.features_b += 68 * f;
+  v.silence_b += f;
+  v.pitch_b += f;
+  v.gains += RN_NB_BANDS * f;
+  v.vad += f;
+  v.nn_act += RN_GRU * f;
+  v.lpc2 += 8 * f;
+  v.train_clean_mem += RN_FRAME_SIZE * f;
+  if (v.debug) v.debug += RN_DBG_FLOATS * f;
+  return v;
 }
 
 int batch_flush_timing(RNNoiseBatch *b) {
@@ -648,16 +727,15 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   return b;
 }
 
+static void host_io_release(RNNoiseBatch *b);
 extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (!b) return;
   DeviceGuard guard(b->device);
   hipDeviceSynchronize();
   for (auto &e : b->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto &e : b->pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  if (b->stage_in) hipFree(b->stage_in);
-  if (b->stage_out) hipFree(b->stage_out);
-  if (b->stage_vad) hipFree(b->stage_vad);
-  if (b->stage_gains) hipFree(b->stage_gains);
+  host_io_release(b);
+  if (b->state_stage) hipFree(b->state_stage);
   if (b->arena) hipFree(b->arena);
   if (b->debug_buf) hipFree(b->debug_buf);
   if (b->side) {
@@ -795,29 +873,118 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   return 0;
 }
 
+// ---- host-fed path (pinned, double-buffered H2D / D2H) ----
+namespace {
+bool host_pinned(const void *p) {  // memory the DMA engines can reach directly (hipHostMalloc / hipHostRegister)
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+static void host_io_release(RNNoiseBatch *b) {
+  RNNoiseBatch::HostIo &io = b->io;
+  for (int k = 0; k < 2; k++) {
+    if (io.d_in[k]) hipFree(io.d_in[k]);
+    if (io.h_in[k]) hipHostFree(io.h_in[k]);
+    if (io.up_done[k]) { hipEventDestroy(io.up_done[k]); hipEventDestroy(io.run_done[k]); hipEventDestroy(io.down_done[k]); }
+  }
+  if (io.up) { hipStreamDestroy(io.up); hipStreamDestroy(io.run); hipStreamDestroy(io.down); }
+  io = RNNoiseBatch::HostIo();
+}
+
+// device (and, for pageable callers, pinned host) staging for two chunks of `frames` frames each: one allocation per
+// side and chunk, carved into in | out | vad | gains
+static int host_io_prepare(RNNoiseBatch *b, int frames, bool bounce) {
+  RNNoiseBatch::HostIo &io = b->io;
+  if (io.chunk_frames >= frames && (!bounce || io.h_in[0])) return 0;
+  const bool had_bounce = io.h_in[0] != nullptr;
+  host_io_release(b);
+  const size_t N = b->n, fr = (size_t)frames, n_in = fr * N * RN_FRAME_SIZE, n_vad = fr * N, n_g = fr * N * RN_NB_BANDS;
+  const size_t total = (2 * n_in + n_vad + n_g) * sizeof(float);
+  HIP_OK(hipStreamCreateWithFlags(&io.up, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&io.run, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&io.down, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) {
+    HIP_OK(hipMalloc((void **)&io.d_in[k], total));
+    io.d_out[k] = io.d_in[k] + n_in;
+    io.d_vad[k] = io.d_out[k] + n_in;
+    io.d_gains[k] = io.d_vad[k] + n_vad;
+    if (bounce || had_bounce) {
+      HIP_OK(hipHostMalloc((void **)&io.h_in[k], total, hipHostMallocDefault));
+      io.h_out[k] = io.h_in[k] + n_in;
+      io.h_vad[k] = io.h_out[k] + n_in;
+      io.h_gains[k] = io.h_vad[k] + n_vad;
+    }
+    HIP_OK(hipEventCreateWithFlags(&io.up_done[k], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&io.run_done[k], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&io.down_done[k], hipEventDisableTiming));
+  }
+  io.chunk_frames = frames;
+  return 0;
+}
+
 extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
                                      int n_frames) {
   if (!b || !out || !in || n_frames < 0) return -1;
   if (n_frames == 0) return 0;
   ON_DEVICE(b->device);
-  const size_t N = b->n;
-  if (b->stage_frames < n_frames) {
-    if (b->stage_in) { hipFree(b->stage_in); hipFree(b->stage_out); hipFree(b->stage_vad); hipFree(b->stage_gains); }
-    b->stage_in = b->stage_out = b->stage_vad = b->stage_gains = nullptr;
-    b->stage_frames = 0;
-    HIP_OK(hipMalloc((void **)&b->stage_in, n_frames * N * RN_FRAME_SIZE * 4));
-    HIP_OK(hipMalloc((void **)&b->stage_out, n_frames * N * RN_FRAME_SIZE * 4));
-    HIP_OK(hipMalloc((void **)&b->stage_vad, n_frames * N * 4));
-    HIP_OK(hipMalloc((void **)&b->stage_gains, n_frames * N * RN_NB_BANDS * 4));
-    b->stage_frames = n_frames;
+  const size_t N = b->n, fsz = N * RN_FRAME_SIZE;
+  // chunks of about 32 MB of PCM each way (at least one frame), two in flight.  Pinned caller memory is used in place;
+  // pageable memory goes through pinned bounce buffers (the copy in and out of them is then the calling thread's work).
+  const int chunk = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, ((size_t)32 << 20) / (fsz * sizeof(float))));
+  const bool direct = host_pinned(in) && host_pinned(out) && (!vad || host_pinned(vad)) && (!gains || host_pinned(gains));
+  if (host_io_prepare(b, chunk, !direct)) return -1;
+  RNNoiseBatch::HostIo &io = b->io;
+  const int n_chunks = (n_frames + chunk - 1) / chunk;
+  auto frames_of = [&](int c) { return std::min(chunk, n_frames - c * chunk); };
+  auto upload = [&](int c) -> int {  // chunk c -> staging set c & 1 (free once chunk c-2 has been downloaded)
+    const int k = c & 1, f = frames_of(c);
+    const float *src = in + (size_t)c * chunk * fsz;
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(io.up, io.run_done[k], 0));  // its kernels no longer read d_in[k]
+    if (!direct) {
+      if (c >= 2) HIP_OK(hipEventSynchronize(io.up_done[k]));          // the bounce buffer has been sent
+      memcpy(io.h_in[k], src, (size_t)f * fsz * sizeof(float));
+      src = io.h_in[k];
+    }
+    HIP_OK(hipMemcpyAsync(io.d_in[k], src, (size_t)f * fsz * sizeof(float), hipMemcpyHostToDevice, io.up));
+    HIP_OK(hipEventRecord(io.up_done[k], io.up));
+    return 0;
+  };
+  auto collect = [&](int c) -> int {  // pageable callers: bounce buffer of chunk c -> caller memory
+    const int k = c & 1, f = frames_of(c);
+    HIP_OK(hipEventSynchronize(io.down_done[k]));
+    memcpy(out + (size_t)c * chunk * fsz, io.h_out[k], (size_t)f * fsz * sizeof(float));
+    if (vad) memcpy(vad + (size_t)c * chunk * N, io.h_vad[k], (size_t)f * N * sizeof(float));
+    if (gains) memcpy(gains + (size_t)c * chunk * N * RN_NB_BANDS, io.h_gains[k], (size_t)f * N * RN_NB_BANDS * sizeof(float));
+    return 0;
+  };
+  if (upload(0)) return -1;
+  for (int c = 0; c < n_chunks; c++) {
+    const int k = c & 1, f = frames_of(c);
+    if (c + 1 < n_chunks && upload(c + 1)) return -1;
+    HIP_OK(hipStreamWaitEvent(io.run, io.up_done[k], 0));
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(io.run, io.down_done[k], 0));  // d_out[k] of chunk c-2 has left
+    if (rnnoise_batch_process_device(b, io.d_out[k], io.d_in[k], io.d_vad[k], io.d_gains[k], f, io.run)) return -1;
+    HIP_OK(hipEventRecord(io.run_done[k], io.run));
+    if (!direct && c >= 2 && collect(c - 2)) return -1;  // frees h_out[k] for the download queued below
+    HIP_OK(hipStreamWaitEvent(io.down, io.run_done[k], 0));
+    float *dst_out = direct ? out + (size_t)c * chunk * fsz : io.h_out[k];
+    HIP_OK(hipMemcpyAsync(dst_out, io.d_out[k], (size_t)f * fsz * sizeof(float), hipMemcpyDeviceToHost, io.down));
+    if (vad) HIP_OK(hipMemcpyAsync(direct ? vad + (size_t)c * chunk * N : io.h_vad[k], io.d_vad[k], (size_t)f * N * sizeof(float),
+                                   hipMemcpyDeviceToHost, io.down));
+    if (gains) HIP_OK(hipMemcpyAsync(direct ? gains + (size_t)c * chunk * N * RN_NB_BANDS : io.h_gains[k], io.d_gains[k],
+                                     (size_t)f * N * RN_NB_BANDS * sizeof(float), hipMemcpyDeviceToHost, io.down));
+    HIP_OK(hipEventRecord(io.down_done[k], io.down));
   }
-  HIP_OK(hipMemcpy(b->stage_in, in, n_frames * N * RN_FRAME_SIZE * 4, hipMemcpyHostToDevice));
-  if (rnnoise_batch_process_device(b, b->stage_out, b->stage_in, b->stage_vad, b->stage_gains, n_frames, nullptr))
-    return -1;
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpy(out, b->stage_out, n_frames * N * RN_FRAME_SIZE * 4, hipMemcpyDeviceToHost));
-  if (vad) HIP_OK(hipMemcpy(vad, b->stage_vad, n_frames * N * 4, hipMemcpyDeviceToHost));
-  if (gains) HIP_OK(hipMemcpy(gains, b->stage_gains, n_frames * N * RN_NB_BANDS * 4, hipMemcpyDeviceToHost));
+  if (!direct)
+    for (int c = std::max(0, n_chunks - 2); c < n_chunks; c++)
+      if (collect(c)) return -1;
+  HIP_OK(hipStreamSynchronize(io.down));
+  HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
   return 0;
 }
 
@@ -878,31 +1045,17 @@ extern "C" int rnnoise_batch_train_features(RNNoiseBatch *b, float *records, con
 #define D2H(dst, src, count) HIP_OK(hipMemcpy(dst, src, (count) * 4, hipMemcpyDeviceToHost))
 #define H2D(dst, src, count) HIP_OK(hipMemcpy(dst, src, (count) * 4, hipMemcpyHostToDevice))
 
+// State migration: one gather / scatter kernel (state_kernels.hip) and one copy per call.  Synchronous with everything
+// the batch has in flight (the caller's streams are not known here, so the device is drained first).
 extern "C" int rnnoise_batch_export_state(RNNoiseBatch *b, int s, float *f) {
   if (!b || !f || s < 0 || s >= b->n) return -1;
   ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
-  const RnGroupDev &g = b->g;
-  const size_t S = s, N = b->n;
-  const int last = (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;  // slot of the most recent frame = the "delayed" spectra
-  {  // un-rotate the pitch ring: pitch_buf[i] = ring[(ring0 + i) % RN_RING_SIZE]
-    float ring[RN_RING_SIZE];
-    D2H(ring, g.pitch_ring + S * RN_RING_SIZE, RN_RING_SIZE);
-    const int ring0 = RN_RING0((b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS);  // newest frame = previous slot
-    for (int i = 0; i < RN_PITCH_BUF_SIZE; i++) f[RN_OFF_PITCH_BUF + i] = ring[(ring0 + i) % RN_RING_SIZE];
-  }
-  memcpy(f + RN_OFF_ANALYSIS, f + RN_OFF_PITCH_BUF + RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, RN_FRAME_SIZE * 4);
-  D2H(f + RN_OFF_SYNTHESIS, g.synth_mem + S * RN_FRAME_SIZE, RN_FRAME_SIZE);
-  D2H(f + RN_OFF_LAST_GAIN, g.last_gain + S, 1);
-  D2H(f + RN_OFF_LAST_PERIOD, g.last_period + S, 1);
-  D2H(f + RN_OFF_MEM_HP, g.mem_hp + 2 * S, 2);
-  D2H(f + RN_OFF_LASTG, g.lastg + S * RN_NB_BANDS, RN_NB_BANDS);
-  D2H(f + RN_OFF_CONV1, g.conv1_state + S * 130, 130);
-  D2H(f + RN_OFF_CONV2, g.conv2_state + S * 256, 256);
-  for (int k = 0; k < 3; k++) D2H(f + RN_OFF_GRU1 + k * RN_GRU, g.gru_state + (k * N + S) * RN_GRU, RN_GRU);
-  D2H(f + RN_OFF_DELAYED_X, g.spec_X[last] + S * RN_SPEC_STRIDE, 962);
-  D2H(f + RN_OFF_DELAYED_P, g.spec_P[last] + S * RN_SPEC_STRIDE, 962);
-  D2H(f + RN_OFF_DELAYED_EX, g.spec_E[last] + S * 96, 96);
+  if (!b->state_stage) HIP_OK(hipMalloc((void **)&b->state_stage, RN_STATE_FLOATS * sizeof(float)));
+  const RnGroupDev v = group_view(b->g, s, 1);
+  HIP_OK(rn_launch_state_gather(&v, b->state_stage, (b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS,
+                                (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS, nullptr));
+  D2H(f, b->state_stage, RN_STATE_FLOATS);  // (a blocking copy on the null stream: ordered after the kernel)
   return 0;
 }
 
@@ -914,26 +1067,12 @@ extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f
   }
   ON_DEVICE(b->device);
   HIP_OK(hipDeviceSynchronize());
-  const RnGroupDev &g = b->g;
-  const size_t S = s, N = b->n;
-  const int last = (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
-  {
-    float ring[RN_RING_SIZE] = {0};
-    const int ring0 = RN_RING0((b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS);
-    for (int i = 0; i < RN_PITCH_BUF_SIZE; i++) ring[(ring0 + i) % RN_RING_SIZE] = f[RN_OFF_PITCH_BUF + i];
-    H2D(g.pitch_ring + S * RN_RING_SIZE, ring, RN_RING_SIZE);
-  }
-  H2D(g.synth_mem + S * RN_FRAME_SIZE, f + RN_OFF_SYNTHESIS, RN_FRAME_SIZE);
-  H2D(g.last_gain + S, f + RN_OFF_LAST_GAIN, 1);
-  H2D(g.last_period + S, f + RN_OFF_LAST_PERIOD, 1);
-  H2D(g.mem_hp + 2 * S, f + RN_OFF_MEM_HP, 2);
-  H2D(g.lastg + S * RN_NB_BANDS, f + RN_OFF_LASTG, RN_NB_BANDS);
-  H2D(g.conv1_state + S * 130, f + RN_OFF_CONV1, 130);
-  H2D(g.conv2_state + S * 256, f + RN_OFF_CONV2, 256);
-  for (int k = 0; k < 3; k++) H2D(g.gru_state + (k * N + S) * RN_GRU, f + RN_OFF_GRU1 + k * RN_GRU, RN_GRU);
-  H2D(g.spec_X[last] + S * RN_SPEC_STRIDE, f + RN_OFF_DELAYED_X, 962);
-  H2D(g.spec_P[last] + S * RN_SPEC_STRIDE, f + RN_OFF_DELAYED_P, 962);
-  H2D(g.spec_E[last] + S * 96, f + RN_OFF_DELAYED_EX, 96);
+  if (!b->state_stage) HIP_OK(hipMalloc((void **)&b->state_stage, RN_STATE_FLOATS * sizeof(float)));
+  H2D(b->state_stage, f, RN_STATE_FLOATS);
+  const RnGroupDev v = group_view(b->g, s, 1);
+  HIP_OK(rn_launch_state_scatter(&v, b->state_stage, (b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS,
+                                 (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS, nullptr));
+  HIP_OK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1079,9 +1218,143 @@ extern "C" RNNModel *rnnoise_model_from_filename(const char *filename) {
   return m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// model == NULL: the reference falls back to its compiled-in weights (include/rnnoise.h:64-76,
+// src/denoise.c:298-303).  Those are a separate download upstream (download_model.sh) and are not
+// compiled in here either; the equivalent is a weight blob found at run time:
+// $RNNOISE_AMD_DEFAULT_MODEL, else weights_blob.bin beside this library (the file name the
+// reference's own dump_weights_blob writes).  Loaded once per process, never freed.
+// ---------------------------------------------------------------------------------------------
+static RNNModel *default_model() {
+  static std::mutex mu;
+  static RNNModel *model = nullptr;
+  static bool tried = false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (tried) return model;
+  tried = true;
+  std::string path;
+  if (const char *e = getenv("RNNOISE_AMD_DEFAULT_MODEL")) path = e;
+  else {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&default_model), &info) && info.dli_fname) {
+      path = info.dli_fname;
+      const size_t slash = path.rfind('/');
+      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/weights_blob.bin";
+    }
+  }
+  if (!path.empty()) model = rnnoise_model_from_filename(path.c_str());
+  if (!model)
+    fprintf(stderr, "[rnnoise_amd] NULL model: no default weight blob (set RNNOISE_AMD_DEFAULT_MODEL or put weights_blob.bin "
+                    "beside the library; tried '%s')\n", path.c_str());
+  return model;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-resident one-stream states (rnnoise_create / rnnoise_destroy)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+StatePool *pool_new(RNNModel *model, int device) {
+  StatePool *p = new StatePool();
+  p->batch = rnnoise_batch_create(model, StatePool::POOL_SLOTS, device);
+  if (!p->batch) {
+    delete p;
+    return nullptr;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok || hipMalloc((void **)&p->d_io, (size_t)StatePool::POOL_SLOTS * 2 * 484 * sizeof(float)) != hipSuccess ||
+      hipMalloc((void **)&p->d_flat, (size_t)StatePool::POOL_SLOTS * StatePool::FLAT_BLK * sizeof(float)) != hipSuccess) {
+    if (p->d_io) hipFree(p->d_io);
+    rnnoise_batch_destroy(p->batch);
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+// a free row of one of the model's pools on device 0 (a new pool when all are full); zeroed like rnnoise_init()
+int pool_acquire(RNNModel *model, StatePool *&pool, int &slot) {
+  std::unique_lock<std::mutex> lk(model->mu);
+  for (int pass = 0; pass < 2; pass++) {
+    for (StatePool *p : model->pools) {
+      std::lock_guard<std::mutex> pl(p->mu);
+      if (~p->used) {
+        slot = __builtin_ctzll(~p->used);
+        p->used |= 1ull << slot;
+        pool = p;
+        return 0;
+      }
+    }
+    if (pass == 0) {
+      lk.unlock();  // rnnoise_batch_create takes the model lock itself
+      StatePool *p = pool_new(model, 0);
+      lk.lock();
+      if (!p) return -1;
+      model->pools.push_back(p);
+    }
+  }
+  return -1;
+}
+
+void pool_release(StatePool *p, int slot) {
+  std::lock_guard<std::mutex> pl(p->mu);
+  p->used &= ~(1ull << slot);
+}
+
+// the stateful arrays of one row back to all-zero (what rnnoise_init does to a DenoiseState, src/denoise.c:286)
+int pool_zero_row(StatePool *p, int slot, hipStream_t st) {
+  const RnGroupDev v = group_view(p->batch->g, slot, 1);
+  const size_t N = p->batch->n;
+  HIP_OK(hipMemsetAsync(v.mem_hp, 0, 2 * 4, st));
+  HIP_OK(hipMemsetAsync(v.pitch_ring, 0, RN_RING_SIZE * 4, st));
+  HIP_OK(hipMemsetAsync(v.synth_mem, 0, RN_FRAME_SIZE * 4, st));
+  HIP_OK(hipMemsetAsync(v.last_gain, 0, 4, st));
+  HIP_OK(hipMemsetAsync(v.last_period, 0, 4, st));
+  HIP_OK(hipMemsetAsync(v.lastg, 0, RN_NB_BANDS * 4, st));
+  HIP_OK(hipMemsetAsync(v.conv1_state, 0, 130 * 4, st));
+  HIP_OK(hipMemsetAsync(v.conv2_state, 0, 256 * 4, st));
+  for (int k = 0; k < 3; k++) HIP_OK(hipMemsetAsync(v.gru_state + k * N * RN_GRU, 0, RN_GRU * 4, st));
+  for (int k = 0; k < RN_SPEC_SLOTS; k++) {
+    HIP_OK(hipMemsetAsync(v.spec_X[k], 0, RN_SPEC_STRIDE * 4, st));
+    HIP_OK(hipMemsetAsync(v.spec_P[k], 0, RN_SPEC_STRIDE * 4, st));
+    HIP_OK(hipMemsetAsync(v.spec_E[k], 0, 96 * 4, st));
+  }
+  return 0;
+}
+
+// one frame of one row: the four kernels of a step on a one-stream view, on `st` (no side streams: a single frame has
+// nothing to overlap with).  The row's frame bookkeeping (parity, ring slot, scratch copy) is the caller's.
+int pool_step(StatePool *p, int slot, int parity, int ring_slot, long frame_no, float *d_out, const float *d_in, float *d_vad,
+              hipStream_t st) {
+  RNNoiseBatch *b = p->batch;
+  RnGroupDev g = group_view(b->g, slot, 1);
+  if (frame_no & 1) {
+    g.features = g.features_b;
+    g.silence = g.silence_b;
+    g.pitch = g.pitch_b;
+  }
+  g.vad = d_vad;
+  const int prev = (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
+  HIP_OK(rn_launch_hp(&g, d_in, ring_slot, st, nullptr, nullptr));
+  HIP_OK(rn_launch_analysis(&g, &b->tb, ring_slot, parity, st, nullptr, nullptr));
+  HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, nullptr, nullptr));
+  HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out, parity, prev, st, nullptr, nullptr));
+  return 0;
+}
+
+}  // namespace
+
 extern "C" void rnnoise_model_free(RNNModel *model) {
   if (!model) return;
-  if (model->scratch) rnnoise_batch_destroy(model->scratch);
+  for (StatePool *p : model->pools) {
+    {
+      DeviceGuard guard(p->batch->device);
+      hipFree(p->d_io);
+      hipFree(p->d_flat);
+    }
+    rnnoise_batch_destroy(p->batch);
+    delete p;
+  }
   for (auto &d : model->dev) {
     DeviceGuard guard(d.device);
     hipFree(d.mem);
@@ -1094,14 +1367,12 @@ extern "C" void rnnoise_model_free(RNNModel *model) {
 extern "C" int rnnoise_get_size(void) { return (int)sizeof(DenoiseState); }
 extern "C" int rnnoise_get_frame_size(void) { return RN_FRAME_SIZE; }
 
+// rnnoise_init() on caller-owned memory (include/rnnoise.h:57,71): there is no rnnoise_uninit, so such a state must not
+// hold library resources -- it stays a self-contained POD and is staged to a pool row for every frame.
 extern "C" int rnnoise_init(DenoiseState *st, RNNModel *model) {
   if (!st) return -1;
   memset(st, 0, sizeof *st);
-  if (!model) {
-    fprintf(stderr, "[rnnoise_amd] rnnoise_init(NULL model): this build has no compiled-in weights; "
-                    "load a blob with rnnoise_model_from_file()\n");
-    return -1;
-  }
+  if (!model && !(model = default_model())) return -1;
   {
     std::lock_guard<std::mutex> lk(model->mu);
     if (model_parse_locked(model)) return -1;
@@ -1115,50 +1386,129 @@ extern "C" int rnnoise_init(DenoiseState *st, RNNModel *model) {
   return 0;
 }
 
+// rnnoise_create(): the state lives in HBM (a row of a StatePool) until rnnoise_destroy().
 extern "C" DenoiseState *rnnoise_create(RNNModel *model) {
-  DenoiseState *st = static_cast<DenoiseState *>(malloc(sizeof(DenoiseState)));
+  if (!model && !(model = default_model())) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(model->mu);
+    if (model_parse_locked(model)) return nullptr;
+  }
+  if (rnnoise_amd_device_count() < 1) {
+    fprintf(stderr, "[rnnoise_amd] no HIP device visible; this library has no CPU path\n");
+    return nullptr;
+  }
+  DenoiseState *st = static_cast<DenoiseState *>(calloc(1, sizeof(DenoiseState)));
   if (!st) return nullptr;
-  if (rnnoise_init(st, model)) {
+  PooledRef &r = st->ref;
+  if (pool_acquire(model, r.pool, r.slot)) {
     free(st);
     return nullptr;
   }
+  DeviceGuard guard(r.pool->batch->device);
+  r.mu = new std::mutex();
+  if (!guard.ok || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void **)&r.h_io, 2 * 484 * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      pool_zero_row(r.pool, r.slot, r.stream) || hipStreamSynchronize(r.stream) != hipSuccess) {
+    if (r.h_io) hipHostFree(r.h_io);
+    if (r.stream) hipStreamDestroy(r.stream);
+    delete r.mu;
+    pool_release(r.pool, r.slot);
+    free(st);
+    return nullptr;
+  }
+  st->magic = kPooledMagic;
+  st->model = model;
   return st;
 }
 
-extern "C" void rnnoise_destroy(DenoiseState *st) { free(st); }
-
-// One frame of one stream: stage the self-contained state into the model's 1-stream batch,
-// run the same three kernels as the batched path, stage it back.  Correct, not fast
-// (the single-frame API cannot express the parallelism the GPU needs).
-extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float *in) {
-  if (!st || st->magic != kStateMagic || !st->model || !out || !in) {
-    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: uninitialised state\n");
-    abort();
-  }
-  RNNModel *m = st->model;
-  RNNoiseBatch *b;
-  {
-    std::unique_lock<std::mutex> lk(m->mu);
-    if (!m->scratch) {
-      lk.unlock();  // rnnoise_batch_create takes the model lock itself
-      RNNoiseBatch *nb = rnnoise_batch_create(m, 1, 0);
-      lk.lock();
-      if (!m->scratch) m->scratch = nb;
-      else if (nb) rnnoise_batch_destroy(nb);
+extern "C" void rnnoise_destroy(DenoiseState *st) {
+  if (!st) return;
+  if (st->magic == kPooledMagic) {
+    PooledRef &r = st->ref;
+    {
+      DeviceGuard guard(r.pool->batch->device);
+      hipStreamSynchronize(r.stream);
+      hipStreamDestroy(r.stream);
+      hipHostFree(r.h_io);
     }
-    b = m->scratch;
+    delete r.mu;
+    pool_release(r.pool, r.slot);
   }
-  if (!b) {
-    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: no GPU batch available (no CPU fallback)\n");
-    abort();
+  free(st);
+}
+
+// One 480-sample frame of one stream (include/rnnoise.h:94).  There is no error channel in this signature: on a GPU
+// failure the frame comes back zeroed with VAD 0 and the reason on stderr (the host process is never aborted).
+static float frame_failed(float *out, const char *why) {
+  fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: %s; returning a zeroed frame\n", why);
+  if (out) memset(out, 0, RN_FRAME_SIZE * sizeof(float));
+  return 0.f;
+}
+
+extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float *in) {
+  if (!st || (st->magic != kStateMagic && st->magic != kPooledMagic) || !st->model || !out || !in)
+    return frame_failed(out, "uninitialised state or NULL buffer");
+  if (st->magic == kPooledMagic) {
+    // device-resident state: 1,920 bytes up, four launches on the state's own stream, 1,924 bytes (frame + VAD) down
+    PooledRef &r = st->ref;
+    std::lock_guard<std::mutex> lk(*r.mu);
+    DeviceGuard guard(r.pool->batch->device);
+    if (!guard.ok) return frame_failed(out, "cannot select the HIP device");
+    float *d_in = r.pool->d_io + (size_t)r.slot * 2 * 484, *d_out = d_in + 484;
+    float *h_in = r.h_io, *h_out = r.h_io + 484;
+    memcpy(h_in, in, RN_FRAME_SIZE * sizeof(float));
+    if (hipMemcpyAsync(d_in, h_in, RN_FRAME_SIZE * sizeof(float), hipMemcpyHostToDevice, r.stream) != hipSuccess ||
+        pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, d_out, d_in, d_out + RN_FRAME_SIZE, r.stream) ||
+        hipMemcpyAsync(h_out, d_out, (RN_FRAME_SIZE + 1) * sizeof(float), hipMemcpyDeviceToHost, r.stream) != hipSuccess ||
+        hipStreamSynchronize(r.stream) != hipSuccess)
+      return frame_failed(out, "GPU step failed");
+    r.parity = (r.parity + 1) % RN_SPEC_SLOTS;
+    r.ring_slot = (r.ring_slot + 1) % RN_RING_SLOTS;
+    r.frame_no++;
+    memcpy(out, h_out, RN_FRAME_SIZE * sizeof(float));
+    return h_out[RN_FRAME_SIZE];
   }
-  static std::mutex frame_mu;  // the scratch batch is shared by every state of this model
-  std::lock_guard<std::mutex> lk(frame_mu);
-  float vad = 0;
-  if (rnnoise_batch_import_state(b, 0, st->state) || rnnoise_batch_process(b, out, in, &vad, nullptr, 1) ||
-      rnnoise_batch_export_state(b, 0, st->state)) {
-    fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: GPU step failed\n");
-    abort();
+  // self-contained state: borrow a pool row for the duration of the call -- state + frame up in one copy, scatter,
+  // the four kernels, gather, state + frame + VAD down in one copy.  Rows are per call, so states on different threads
+  // proceed concurrently.
+  RNNModel *m = st->model;
+  StatePool *pool = nullptr;
+  int slot = -1;
+  if (pool_acquire(m, pool, slot)) return frame_failed(out, "no GPU state row available (no CPU fallback)");
+  struct Scratch {  // per-thread: a stream and a pinned staging block, created on first use
+    hipStream_t stream = nullptr;
+    float *h = nullptr;
+    int device = -1;
+  };
+  static thread_local Scratch sc;
+  float vad = 0.f;
+  bool ok = false;
+  {
+    DeviceGuard guard(pool->batch->device);
+    constexpr size_t IO = StatePool::FLAT_IO, UP = IO + RN_FRAME_SIZE, DOWN = UP + 1;
+    if (guard.ok && (sc.stream || (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) == hipSuccess &&
+                                   hipHostMalloc((void **)&sc.h, 2 * StatePool::FLAT_BLK * sizeof(float), hipHostMallocDefault) == hipSuccess))) {
+      float *d_blk = pool->d_flat + (size_t)slot * StatePool::FLAT_BLK, *d_io = d_blk + IO;  // frame processed in place
+      const RnGroupDev v = group_view(pool->batch->g, slot, 1);
+      // conventions of a freshly scattered row: its newest frame sits in ring slot 5 and spectra slot 2, so the next frame
+      // goes to ring slot 0 / spectra slot 0 and leaves its own "delayed" spectra in slot 0
+      float *hu = sc.h, *hd = sc.h + StatePool::FLAT_BLK;
+      memcpy(hu, st->state, RN_STATE_FLOATS * sizeof(float));
+      memcpy(hu + IO, in, RN_FRAME_SIZE * sizeof(float));
+      ok = hipMemcpyAsync(d_blk, hu, UP * sizeof(float), hipMemcpyHostToDevice, sc.stream) == hipSuccess &&
+           rn_launch_state_scatter(&v, d_blk, RN_RING_SLOTS - 1, RN_SPEC_SLOTS - 1, sc.stream) == hipSuccess &&
+           pool_step(pool, slot, 0, 0, 0, d_io, d_io, d_io + RN_FRAME_SIZE, sc.stream) == 0 &&
+           rn_launch_state_gather(&v, d_blk, 0, 0, sc.stream) == hipSuccess &&
+           hipMemcpyAsync(hd, d_blk, DOWN * sizeof(float), hipMemcpyDeviceToHost, sc.stream) == hipSuccess &&
+           hipStreamSynchronize(sc.stream) == hipSuccess;
+      if (ok) {
+        memcpy(st->state, hd, RN_STATE_FLOATS * sizeof(float));
+        memcpy(out, hd + IO, RN_FRAME_SIZE * sizeof(float));
+        vad = hd[IO + RN_FRAME_SIZE];
+      }
+    }
   }
+  pool_release(pool, slot);
+  if (!ok) return frame_failed(out, "GPU step failed");
   return vad;
 }

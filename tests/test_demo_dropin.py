@@ -53,3 +53,57 @@ def test_demo_output_is_byte_identical(tmp_path):
     want = want[1:].astype(np.int16).reshape(-1)  # C (short) cast truncates toward zero, like astype
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+REF_DEMO = os.path.join(ROOT, "oracle", "_ref", "rnnoise_demo_ref")
+REF_LIBDIR = os.path.join(ROOT, "oracle", "_ref", "soname")
+
+
+def test_our_library_carries_the_reference_soname():
+    """configure.ac:41-43 (libtool 4:1:4) installs librnnoise.so.0; ours must be loadable under that name"""
+    so = os.path.join(ROOT, "rnnoise_amd", "librnnoise.so.0")
+    assert os.path.exists(so), "build() did not produce rnnoise_amd/librnnoise.so.0"
+    dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "Library soname: [librnnoise.so.0]" in dyn
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for sym in ("rnnoise_create", "rnnoise_process_frame", "rnnoise_destroy", "rnnoise_init", "rnnoise_get_size"):
+        assert f" T {sym}" in nm
+
+
+@pytest.mark.gpu
+def test_already_linked_reference_demo_runs_on_our_library(tmp_path):
+    """The reference's demo, built and linked against the REFERENCE's librnnoise.so.0 (no rpath, NULL model = compiled-in
+    weights), run twice: on the reference library, and with LD_LIBRARY_PATH pointing at ours plus the default-model blob.
+    Same bytes out.  10 s of audio = BASELINE configs[0]."""
+    if not (os.path.exists(REF_DEMO) and os.path.exists(os.path.join(REF_LIBDIR, "librnnoise.so.0"))):
+        pytest.skip("oracle/_ref/rnnoise_demo_ref not built (needs the reference sources at build time)")
+    blob = load_blob("default")
+    (tmp_path / "default.blob").write_bytes(blob)
+    T = 1000
+    synth.stream_pcm(5, T, lead_silence=10).tofile(tmp_path / "in.raw")
+    needed = subprocess.run(["readelf", "-d", REF_DEMO], capture_output=True, text=True).stdout
+    assert "librnnoise.so.0" in needed and "RPATH" not in needed and "RUNPATH" not in needed
+    base = {k: v for k, v in os.environ.items() if k != "LD_LIBRARY_PATH"}
+    subprocess.check_call([REF_DEMO, "in.raw", "ref.raw"], cwd=tmp_path, timeout=300,
+                          env=dict(base, LD_LIBRARY_PATH=REF_LIBDIR))
+    import time
+    t0 = time.perf_counter()
+    subprocess.check_call([REF_DEMO, "in.raw", "ours.raw"], cwd=tmp_path, timeout=600,
+                          env=dict(base, LD_LIBRARY_PATH=os.path.join(ROOT, "rnnoise_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+                                   RNNOISE_AMD_DEFAULT_MODEL=str(tmp_path / "default.blob")))
+    dt = time.perf_counter() - t0
+    ref = (tmp_path / "ref.raw").read_bytes()
+    ours = (tmp_path / "ours.raw").read_bytes()
+    # The parity contract is pinned to the x86 profile of the host that produced the goldens (its `rcpps` table, SURVEY
+    # fact 6): the oracle carries that table, the reference library running on THIS box's CPU may not (Intel build host vs
+    # AMD EPYC GPU box).  So: ours == oracle always; ours == the reference run here whenever that run equals the oracle.
+    from oracle.binding import Oracle
+    pcm = np.fromfile(tmp_path / "in.raw", dtype=np.int16)
+    want = Oracle(blob).run(pcm.astype(np.float32).reshape(T, 480))["out"][1:].astype(np.int16).tobytes()
+    assert len(ref) == (T - 1) * 480 * 2 and len(ours) == len(ref)
+    assert ours == want, "already-linked reference demo on our library: bytes differ from the oracle"
+    same_host_profile = ref == want
+    if same_host_profile:
+        assert ours == ref
+    print(f"configs[0]: {T} frames through the pooled drop-in path in {dt:.2f} s wall ({T / dt:.0f} frames/s incl. process "
+          f"start); reference library on this host {'matches' if same_host_profile else 'differs from (different rcpps)'} the pinned profile")

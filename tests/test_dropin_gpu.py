@@ -1,0 +1,161 @@
+"""GPU suite: the rnnoise.h drop-in boundary (reference include/rnnoise.h:51-125) on device-resident pooled states,
+self-contained caller-memory states, the NULL-model fallback, concurrent states on several threads, and the host-fed
+batched path (pinned / pageable memory, several chunks in flight)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bits_equal
+from oracle.binding import Oracle
+from rnnoise_amd import capi, synth
+from test_gpu_parity import oracle_run
+
+pytestmark = pytest.mark.gpu
+FP = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def model(blob_default):
+    return capi.Model(blob_default)
+
+
+def test_pooled_states_on_four_threads(model, blob_default):
+    """70 rnnoise_create()d states (more than one 64-row pool), driven from 4 threads at once: every stream gets the
+    oracle's bits -- states are independent, and no global lock serialises them into one another's data"""
+    T, n = 12, 70
+    pcm = [synth.stream_pcm(s % 9, T, lead_silence=s % 3).astype(np.float32).reshape(T, 480) for s in range(n)]
+    want = {}
+    for s in range(n):
+        if (s % 9, s % 3) not in want:
+            want[(s % 9, s % 3)] = Oracle(blob_default).run(pcm[s])
+    states = [capi.DenoiseState(model) for _ in range(n)]
+    got_out = [np.zeros((T, 480), np.float32) for _ in range(n)]
+    got_vad = [np.zeros(T, np.float32) for _ in range(n)]
+    errs = []
+
+    def work(tid):
+        try:
+            for t in range(T):
+                for s in range(tid, n, 4):
+                    y, v = states[s].process_frame(pcm[s][t])
+                    got_out[s][t], got_vad[s][t] = y, v
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for s in range(n):
+        ref = want[(s % 9, s % 3)]
+        assert_bits_equal(got_out[s], ref["out"], f"pcm of state {s}")
+        assert_bits_equal(got_vad[s], ref["vad"], f"vad of state {s}")
+    for st in states:
+        st.close()
+    # rows are recycled zeroed: a new state starts from the rnnoise_init() state again
+    st = capi.DenoiseState(model)
+    y, v = st.process_frame(pcm[3][0])
+    assert_bits_equal(y, Oracle(blob_default).run(pcm[3][:1])["out"][0], "first frame of a recycled row")
+
+
+def test_caller_memory_states_interleaved(model, blob_default):
+    """rnnoise_get_size() + rnnoise_init() on caller memory (rnnoise.h:57,71): self-contained POD, may be copied"""
+    L = capi.lib()
+    T = 10
+    pcm = [synth.stream_pcm(20 + k, T, lead_silence=1).astype(np.float32).reshape(T, 480) for k in range(2)]
+    want = [Oracle(blob_default).run(p) for p in pcm]
+    size = L.rnnoise_get_size()
+    bufs = [(C.c_char * size)() for _ in range(2)]
+    for b in bufs:
+        assert L.rnnoise_init(C.cast(b, C.c_void_p), model.h) == 0
+    for t in range(T):
+        if t == 5:  # a state in caller memory is plain data: moving it must not matter
+            moved = (C.c_char * size)()
+            C.memmove(moved, bufs[0], size)
+            bufs[0] = moved
+        for k in range(2):
+            x = pcm[k][t].copy()
+            L.rnnoise_process_frame.restype = C.c_float
+            v = L.rnnoise_process_frame(C.cast(bufs[k], C.c_void_p), x.ctypes.data_as(FP), x.ctypes.data_as(FP))
+            assert_bits_equal(x, want[k]["out"][t], f"state {k} frame {t}")
+            assert np.float32(v).view(np.uint32) == want[k]["vad"][t].view(np.uint32)
+
+
+def test_null_model_uses_the_default_blob(tmp_path, blob_default):
+    """model == NULL (rnnoise.h:64-76): $RNNOISE_AMD_DEFAULT_MODEL stands in for the compiled-in weights; without it the
+    call fails cleanly (NULL / -1) instead of crashing"""
+    blob_path = tmp_path / "weights_blob.bin"
+    blob_path.write_bytes(blob_default)
+    code = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r)
+from rnnoise_amd import capi, synth
+L = capi.lib()
+st = L.rnnoise_create(None)
+print("CREATE", bool(st))
+if st:
+    x = synth.stream_pcm(4, 3).astype(np.float32).reshape(3, 480)
+    out = []
+    for t in range(3):
+        y = x[t].copy()
+        L.rnnoise_process_frame(st, capi._fp(y), capi._fp(y))
+        out.append(y)
+    print("CRC", __import__("zlib").crc32(np.stack(out).tobytes()))
+    L.rnnoise_destroy(st)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, RNNOISE_AMD_DEFAULT_MODEL=str(blob_path)), timeout=300)
+    assert r.returncode == 0 and "CREATE True" in r.stdout, r.stdout + r.stderr
+    import zlib
+    x = synth.stream_pcm(4, 3).astype(np.float32).reshape(3, 480)
+    assert f"CRC {zlib.crc32(Oracle(blob_default).run(x)['out'].tobytes())}" in r.stdout
+    env = {k: v for k, v in os.environ.items() if k != "RNNOISE_AMD_DEFAULT_MODEL"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "CREATE False" in r.stdout and "no default weight blob" in r.stderr, r.stdout + r.stderr
+
+
+def test_bad_state_returns_a_zeroed_frame_instead_of_aborting():
+    L = capi.lib()
+    junk = (C.c_char * L.rnnoise_get_size())()
+    x = np.ones(480, np.float32)
+    L.rnnoise_process_frame.restype = C.c_float
+    v = L.rnnoise_process_frame(C.cast(junk, C.c_void_p), x.ctypes.data_as(FP), x.ctypes.data_as(FP))
+    assert v == 0.0 and not x.any()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_fed_path_chunks_in_flight(model, blob_default, pinned):
+    """rnnoise_batch_process: 8192 streams x 12 frames = 6 chunks of 32 MB through the double-buffered pipeline, from
+    pageable memory (bounce buffers) and from pinned memory (direct DMA); replicas stay identical and match the oracle"""
+    torch = pytest.importorskip("torch")
+    N, T = 8192, 12
+    base = synth.batch_pcm(range(8), T, lead_silence=1)
+    pcm = np.ascontiguousarray(np.tile(base, (1, N // 8, 1)))
+    b = capi.Batch(model, N)
+    if pinned:
+        t_in = torch.from_numpy(pcm).pin_memory()
+        t_out = torch.empty_like(t_in).pin_memory()
+        t_vad = torch.empty((T, N)).pin_memory()
+        t_g = torch.empty((T, N, 32)).pin_memory()
+        assert capi.lib().rnnoise_batch_process(b.h, C.cast(t_out.data_ptr(), FP), C.cast(t_in.data_ptr(), FP),
+                                                C.cast(t_vad.data_ptr(), FP), C.cast(t_g.data_ptr(), FP), T) == 0
+        out, vad, gains = t_out.numpy(), t_vad.numpy(), t_g.numpy()
+    else:
+        out, vad, gains = b.process(pcm)
+    o4 = out.reshape(T, N // 8, 8, 480).view(np.uint32)
+    assert (o4 == o4[:, :1]).all()
+    want = oracle_run(blob_default, base, collect_state=False)
+    assert_bits_equal(out[:, :8], want["out"], "pcm")
+    assert_bits_equal(out[:, -8:], want["out"], "pcm of the last block")
+    assert_bits_equal(vad[:, :8], want["vad"], "vad")
+    assert_bits_equal(gains[:, 8:16], want["gains"], "gains")
+    # a second call continues the streams (state carried across calls and chunk boundaries)
+    out2, _, _ = b.process(pcm[:2])
+    o = Oracle(blob_default)
+    ref2 = o.run(np.concatenate([base[:, 3], base[:2, 3]]))["out"][T:]
+    assert_bits_equal(out2[:, 3], ref2, "continuation")
