@@ -64,6 +64,14 @@ RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);
  * fraction reported by bench.py. */
 RNNOISE_EXPORT long rnnoise_model_weight_bytes(RNNModel *model);
 
+/* GPU-native packed model "RNPK" (SURVEY 8f row f2): the layers already in their device layouts (int8 blocks + column
+ * tables, zero-filled MFMA A-fragment order, row sums), behind a header {magic "RNPK", version, architecture dims, W,
+ * per-layer offsets}.  rnnoise_model_from_buffer / _file / _filename accept a pack wherever they accept a "DNNw" blob
+ * (reference format: src/write_weights.c:46-69); loading one skips the blob walk and the re-layout.
+ * Returns the pack size in bytes; writes it only if cap suffices (out == NULL sizes the buffer).  -1 on a bad model.
+ * Host-only: no GPU needed.  `python -m rnnoise_amd.blob pack in.blob out.rnpk` is the command-line form. */
+RNNOISE_EXPORT long rnnoise_amd_model_pack(RNNModel *model, void *out, long cap);
+
 /* Training-feature extraction (the inner loop of the reference's src/dump_features.c:466-491, a
  * TRAINING=1 build of denoise.c): per frame and stream, Ey from the CLEAN frame, the 65 features
  * from the NOISY frame (no silence short-cut), the 32 band-gain targets and the VAD target passed

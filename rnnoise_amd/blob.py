@@ -15,6 +15,7 @@ test models of any density can be produced where the reference tree is not mount
 
 CLI:  python -m rnnoise_amd.blob info  model.blob
       python -m rnnoise_amd.blob synth out.blob [--seed S] [--density D] [--boost B]
+      python -m rnnoise_amd.blob pack  model.blob out.rnpk     ("DNNw" -> GPU-native "RNPK" pack, include/rnnoise_amd.h)
 """
 from __future__ import annotations
 
@@ -174,6 +175,46 @@ def describe(blob: bytes) -> str:
     return "\n".join(lines)
 
 
+PACK_LAYERS = ["conv1", "conv2", "gru1_input", "gru1_recurrent", "gru2_input", "gru2_recurrent", "gru3_input",
+               "gru3_recurrent", "dense_out", "vad_dense"]
+_PACK_HEAD = struct.Struct("<4sI8IqQ")       # magic, version, dims[8], weight_bytes, payload_bytes
+_PACK_LAYER = struct.Struct("<9Q4I4i")       # 9 offsets, 4 flags, nin, nout, nblocks, pad
+
+
+def pack(blob: bytes) -> bytes:
+    """"DNNw" blob -> GPU-native "RNPK" pack.  The layouts are produced by the library itself (the same code that stages a
+    blob for the GPU: rnnoise_amd/csrc/shim.cpp stage_linear), so a pack is bit-for-bit what a blob load would upload."""
+    from . import capi
+    m = capi.Model(blob)
+    try:
+        return m.pack()
+    finally:
+        m.close()
+
+
+def read_pack_header(data: bytes):
+    """header of an "RNPK" pack: dict(version, dims, weight_bytes, payload_bytes, layers=[dict(name, nin, nout, nblocks, ...)])"""
+    if data[:4] != b"RNPK" or len(data) < _PACK_HEAD.size + 10 * _PACK_LAYER.size:
+        raise ValueError("not an RNPK pack")
+    f = _PACK_HEAD.unpack_from(data, 0)
+    layers = []
+    for i, name in enumerate(PACK_LAYERS):
+        v = _PACK_LAYER.unpack_from(data, _PACK_HEAD.size + i * _PACK_LAYER.size)
+        layers.append(dict(name=name, offsets=dict(zip(("bias", "fw", "scale", "diag", "w", "wmf", "rowsum", "grp", "cols"), v[:9])),
+                           is_int8=bool(v[12]), has_diag=bool(v[10]), nin=v[13], nout=v[14], nblocks=v[15]))
+    return dict(version=f[1], dims=list(f[2:10]), weight_bytes=f[10], payload_bytes=f[11], layers=layers,
+                header_bytes=_PACK_HEAD.size + 10 * _PACK_LAYER.size)
+
+
+def describe_pack(data: bytes) -> str:
+    h = read_pack_header(data)
+    lines = [f"RNPK version {h['version']}, dims {h['dims']}, W = {h['weight_bytes']} bytes/frame, payload {h['payload_bytes']} bytes"]
+    for l in h["layers"]:
+        kind = f"int8, {l['nblocks']} blocks of 8x4 (+ {l['nin']}x{l['nout']} MFMA image)" if l["is_int8"] else "float"
+        lines.append(f"  {l['name']:<16} {l['nin']:5d} -> {l['nout']:5d}  {kind}{', diagonal' if l['has_diag'] else ''}")
+    return "\n".join(lines)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -184,9 +225,17 @@ def main(argv=None):
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--density", type=float, default=1 / 3)
     p.add_argument("--boost", type=float, default=3.0)
+    p = sub.add_parser("pack")
+    p.add_argument("blob")
+    p.add_argument("out")
     a = ap.parse_args(argv)
     if a.cmd == "info":
-        print(describe(open(a.blob, "rb").read()))
+        data = open(a.blob, "rb").read()
+        print(describe_pack(data) if data[:4] == b"RNPK" else describe(data))
+    elif a.cmd == "pack":
+        b = pack(open(a.blob, "rb").read())
+        open(a.out, "wb").write(b)
+        print(f"wrote {a.out}: {len(b)} bytes ({describe_pack(b).splitlines()[0]})")
     else:
         b = synth_model(a.seed, a.density, a.boost)
         open(a.out, "wb").write(b)

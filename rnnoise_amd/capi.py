@@ -32,7 +32,7 @@ EXPORTS = [
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
-    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft", "rnnoise_amd_model_pack",
 ]
 
 
@@ -84,6 +84,8 @@ def lib():
         L.rnnoise_batch_export_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_import_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_set_nn_path.argtypes = [vp, C.c_int]
+        L.rnnoise_amd_model_pack.restype = C.c_long
+        L.rnnoise_amd_model_pack.argtypes = [vp, vp, C.c_long]
         L.rnnoise_model_weight_bytes.restype = C.c_long
         L.rnnoise_model_weight_bytes.argtypes = [vp]
         L.rnnoise_batch_debug_last.argtypes = [vp, fp, ip, ip]
@@ -117,6 +119,16 @@ class Model:
         if w < 0:
             raise ValueError("weight blob rejected")
         return int(w)
+
+    def pack(self) -> bytes:
+        """the model as a GPU-native "RNPK" pack (rnnoise_amd_model_pack); loadable wherever a blob is"""
+        n = lib().rnnoise_amd_model_pack(self.h, None, 0)
+        if n <= 0:
+            raise ValueError("weight blob rejected")
+        buf = C.create_string_buffer(n)
+        if lib().rnnoise_amd_model_pack(self.h, buf, n) != n:
+            raise RuntimeError("rnnoise_amd_model_pack failed")
+        return buf.raw
 
     def close(self):
         if getattr(self, "h", None):
@@ -166,6 +178,14 @@ class Batch:
         if lib().rnnoise_batch_process(self.h, _fp(out), _fp(pcm), _fp(vad), _fp(gains), T):
             raise RuntimeError("rnnoise_batch_process failed")
         return out, vad, gains
+
+    def process_into(self, out_ptr: int, in_ptr: int, vad_ptr: int, gains_ptr: int, n_frames: int):
+        """rnnoise_batch_process on raw HOST pointers (ints).  Pinned memory (hipHostMalloc / torch pin_memory) is read
+        and written by DMA in place; pageable memory goes through the library's pinned bounce buffers."""
+        fp = C.POINTER(C.c_float)
+        if lib().rnnoise_batch_process(self.h, C.cast(out_ptr, fp), C.cast(in_ptr, fp), C.cast(vad_ptr or None, fp),
+                                       C.cast(gains_ptr or None, fp), n_frames):
+            raise RuntimeError("rnnoise_batch_process failed")
 
     def process_device(self, d_out: int, d_in: int, d_vad: int, d_gains: int, n_frames: int, stream: int = 0):
         """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle)."""

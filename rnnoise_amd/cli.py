@@ -23,33 +23,36 @@ FRAME = capi.FRAME
 
 def denoise_files(model_blob: bytes, inputs, out_dir: str, chunk_frames: int = 100, device: int = 0,
                   vad_csv: bool = False):
+    """Streams the files through the batch chunk by chunk: at most `chunk_frames` frames of every file are in host memory
+    at a time (two staging buffers, reused), whatever the file lengths."""
     os.makedirs(out_dir, exist_ok=True)
-    pcm = [np.fromfile(p, dtype=np.int16) for p in inputs]
-    n_frames = [len(x) // FRAME for x in pcm]  # partial tail dropped (rnnoise_demo.c:55)
-    N, T = len(pcm), max(n_frames + [0])
+    n_frames = [os.path.getsize(p) // 2 // FRAME for p in inputs]  # partial tail dropped (rnnoise_demo.c:55)
+    N, T = len(inputs), max(n_frames + [0])
     model = capi.Model(model_blob)
     batch = capi.Batch(model, N, device=device)
+    ins = [open(p, "rb") for p in inputs]
     outs = [open(os.path.join(out_dir, os.path.basename(p) + ".denoised.raw"), "wb") for p in inputs]
-    vads = [[] for _ in inputs]
+    vfs = [open(os.path.join(out_dir, os.path.basename(p) + ".vad.csv"), "w") for p in inputs] if vad_csv else None
+    buf = np.zeros((min(chunk_frames, max(T, 1)), N, FRAME), np.float32)
     for t0 in range(0, T, chunk_frames):
         tn = min(chunk_frames, T - t0)
-        buf = np.zeros((tn, N, FRAME), np.float32)
-        for s, x in enumerate(pcm):
+        chunk = buf[:tn]
+        chunk[:] = 0  # a stream whose file has ended is fed zeros and produces no more output
+        for s, f in enumerate(ins):
             k = max(0, min(tn, n_frames[s] - t0))
             if k:
-                buf[:k, s] = x[t0 * FRAME:(t0 + k) * FRAME].reshape(k, FRAME)
-        out, vad, _ = batch.process(buf, want_gains=False)
+                x = np.frombuffer(f.read(k * FRAME * 2), dtype=np.int16)
+                chunk[:k, s] = x.reshape(k, FRAME)
+        out, vad, _ = batch.process(chunk, want_gains=False)
         for s in range(N):
             k = max(0, min(tn, n_frames[s] - t0))
             first = 1 if t0 == 0 else 0  # the demo drops the first output frame (rnnoise_demo.c:59-60)
             if k > first:
                 outs[s].write(out[first:k, s].astype(np.int16).tobytes())  # C (short) cast: truncation
-            vads[s].extend(vad[:k, s].tolist())
-    for f in outs:
+            if vfs and k:
+                vfs[s].write("".join(f"{v:.6f}\n" for v in vad[:k, s]))
+    for f in ins + outs + (vfs or []):
         f.close()
-    if vad_csv:
-        for p, v in zip(inputs, vads):
-            np.savetxt(os.path.join(out_dir, os.path.basename(p) + ".vad.csv"), np.asarray(v), fmt="%.6f")
     batch.close()
     model.close()
     return n_frames

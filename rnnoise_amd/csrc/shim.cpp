@@ -423,6 +423,7 @@ struct DeviceModel {
 // public types
 // =============================================================================================
 struct StatePool;
+namespace { struct StagedModel; }
 struct RNNModel {
   const void *const_blob = nullptr;  // borrowed (rnnoise_model_from_buffer)
   void *blob = nullptr;              // owned (rnnoise_model_from_file)
@@ -430,7 +431,9 @@ struct RNNModel {
   FILE *file = nullptr;
   std::mutex mu;
   int parsed = 0;  // 0 not yet, 1 ok, -1 rejected
-  HostModel host;
+  HostModel host;                  // layer views into a "DNNw" blob (unused for a packed model)
+  StagedModel *staged = nullptr;   // device layout of every layer, built from the blob or taken from an "RNPK" pack
+  long weight_bytes = 0;           // SURVEY 8d "W"
   std::vector<DeviceModel> dev;
   std::vector<StatePool *> pools;  // device-resident one-stream states behind rnnoise_create / rnnoise_process_frame
   const void *bytes() const { return blob ? blob : const_blob; }
@@ -516,8 +519,110 @@ static const uint32_t kPooledMagic = 0x524e4e50u;  // "RNNP": row of a StatePool
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------
+// "RNPK": the GPU-native packed model.  What model_on_device() uploads -- every layer already in
+// its device layout: int8 blocks in exporter order + column / group tables for the vector path, the same weights
+// zero-filled to dense and pre-swizzled into MFMA A-fragment order, row sums, float layers as they are -- preceded by a
+// header with a version tag, the architecture the layouts were made for and the per-layer offsets.  Loading a pack skips
+// the blob walk and the re-layout; rnnoise_model_from_buffer / _file / _filename accept either format.
+// ---------------------------------------------------------------------------------------------
+struct PackLayer {
+  uint64_t bias, fw, scale, diag, w, wmf, rowsum, grp, cols;
+  uint32_t has_fw, has_diag, has_cols, is_int8;
+  int32_t nin, nout, nblocks, pad;
+};
+struct PackHeader {
+  char magic[4];        // "RNPK"
+  uint32_t version;     // RN_PACK_VERSION
+  uint32_t dims[8];     // conv1 in/out, conv2 in/out, GRU size, concat size, bands, MFMA k-tile (64)
+  int64_t weight_bytes; // SURVEY 8d "W" of the source blob
+  uint64_t payload_bytes;
+  PackLayer layers[10]; // conv1, conv2, gru1..3 input, gru1..3 recurrent (interleaved in, rec), dense_out, vad_dense
+};
+static const uint32_t RN_PACK_VERSION = 1;
+static const uint32_t kPackDims[8] = {RN_CONV1_K, RN_CONV1_OUT, RN_CONV2_K, RN_CONV2_OUT, RN_GRU, RN_CAT, RN_NB_BANDS, 64};
+
+struct StagedModel {
+  Staging st;
+  DevLinearOffsets off[10];
+  HostLinear lin[10];  // only nin / nout / nblocks are meaningful for a model that came from a pack
+};
+
+long host_weight_bytes(const HostModel &h) {
+  long w = linear_weight_bytes(h.conv1) + linear_weight_bytes(h.conv2) + linear_weight_bytes(h.dense_out) +
+           linear_weight_bytes(h.vad_dense);
+  for (int k = 0; k < 3; k++) w += linear_weight_bytes(h.gru_in[k]) + linear_weight_bytes(h.gru_rec[k]);
+  return w;
+}
+
+void stage_model(const HostModel &h, StagedModel &sm) {
+  const HostLinear *order[10] = {&h.conv1, &h.conv2, &h.gru_in[0], &h.gru_rec[0], &h.gru_in[1], &h.gru_rec[1],
+                                 &h.gru_in[2], &h.gru_rec[2], &h.dense_out, &h.vad_dense};
+  for (int i = 0; i < 10; i++) {
+    sm.lin[i] = *order[i];
+    sm.off[i] = stage_linear(sm.st, *order[i]);
+  }
+}
+
+bool is_pack(const void *p, int len) { return p && len >= (int)sizeof(PackHeader) && !memcmp(p, "RNPK", 4); }
+
+// header + payload of a pack -> staged form (bounds-checked: a pack is untrusted input like a blob)
+bool unpack_model(const void *p, int len, StagedModel &sm, long &weight_bytes) {
+  PackHeader h;
+  memcpy(&h, p, sizeof h);
+  if (h.version != RN_PACK_VERSION || memcmp(h.dims, kPackDims, sizeof kPackDims)) return false;
+  if (h.payload_bytes != (uint64_t)len - sizeof h || h.weight_bytes <= 0) return false;
+  const uint64_t n = h.payload_bytes;
+  static const int want[10][2] = {{RN_CONV1_K, RN_CONV1_OUT}, {RN_CONV2_K, RN_CONV2_OUT}, {RN_GRU, RN_GRU3}, {RN_GRU, RN_GRU3},
+                                  {RN_GRU, RN_GRU3}, {RN_GRU, RN_GRU3}, {RN_GRU, RN_GRU3}, {RN_GRU, RN_GRU3},
+                                  {RN_CAT, RN_NB_BANDS}, {RN_CAT, 1}};
+  for (int i = 0; i < 10; i++) {
+    const PackLayer &l = h.layers[i];
+    if (l.nin != want[i][0] || l.nout != want[i][1] || l.nblocks < 0 || l.nblocks > (l.nin / 4) * (l.nout / 8)) return false;
+    auto fits = [&](uint64_t off, uint64_t bytes) { return off <= n && bytes <= n - off && !(off & 15); };
+    const uint64_t no = l.nout, ni = l.nin;
+    if (!fits(l.bias, 4 * no)) return false;
+    if (l.is_int8) {
+      if (!fits(l.scale, 4 * no) || !fits(l.w, 32ull * l.nblocks) || !fits(l.wmf, no * ni) || !fits(l.rowsum, 4 * no) ||
+          !fits(l.grp, 4 * (no / 8 + 1)) || !fits(l.cols, 2ull * l.nblocks))
+        return false;
+      if (l.has_diag && !fits(l.diag, 4 * no)) return false;
+      // the group / column tables index the weight array: they must stay inside it
+      const int32_t *grp = reinterpret_cast<const int32_t *>(static_cast<const uint8_t *>(p) + sizeof h + l.grp);
+      const uint16_t *cols = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(p) + sizeof h + l.cols);
+      if (grp[0] != 0 || grp[no / 8] != l.nblocks) return false;
+      for (uint64_t gidx = 0; gidx < no / 8; gidx++)
+        if (grp[gidx + 1] < grp[gidx]) return false;
+      for (int b = 0; b < l.nblocks; b++)
+        if (cols[b] + 3 >= l.nin || (cols[b] & 3)) return false;
+    } else if (!l.has_fw || !fits(l.fw, 4 * no * ni)) {
+      return false;
+    }
+    DevLinearOffsets &o = sm.off[i];
+    o.bias = l.bias; o.fw = l.fw; o.scale = l.scale; o.diag = l.diag; o.w = l.w; o.wmf = l.wmf; o.rowsum = l.rowsum;
+    o.grp = l.grp; o.cols = l.cols;
+    o.has_fw = l.has_fw; o.has_diag = l.has_diag; o.has_cols = l.has_cols; o.is_int8 = l.is_int8;
+    sm.lin[i] = HostLinear();
+    sm.lin[i].nin = l.nin;
+    sm.lin[i].nout = l.nout;
+    sm.lin[i].nblocks = l.nblocks;
+  }
+  const uint8_t *payload = static_cast<const uint8_t *>(p) + sizeof h;
+  sm.st.bytes.assign(payload, payload + n);
+  weight_bytes = (long)h.weight_bytes;
+  return true;
+}
+
 int model_parse_locked(RNNModel *m) {
-  if (m->parsed == 0) m->parsed = host_model_from_blob(m->host, m->bytes(), m->blob_len) ? 1 : -1;
+  if (m->parsed == 0) {
+    if (is_pack(m->bytes(), m->blob_len)) {
+      m->staged = new StagedModel();
+      m->parsed = unpack_model(m->bytes(), m->blob_len, *m->staged, m->weight_bytes) ? 1 : -1;
+    } else {
+      m->parsed = host_model_from_blob(m->host, m->bytes(), m->blob_len) ? 1 : -1;
+      if (m->parsed == 1) m->weight_bytes = host_weight_bytes(m->host);
+    }
+  }
   return m->parsed == 1 ? 0 : -1;
 }
 
@@ -529,28 +634,20 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
       out = d.dev;
       return 0;
     }
-  const HostModel &h = m->host;
-  Staging st;
-  DevLinearOffsets oc1 = stage_linear(st, h.conv1), oc2 = stage_linear(st, h.conv2), ogi[3], ogr[3];
-  for (int k = 0; k < 3; k++) {
-    ogi[k] = stage_linear(st, h.gru_in[k]);
-    ogr[k] = stage_linear(st, h.gru_rec[k]);
+  if (!m->staged) {  // "DNNw" blob: re-layout once per process
+    m->staged = new StagedModel();
+    stage_model(m->host, *m->staged);
   }
-  DevLinearOffsets od = stage_linear(st, h.dense_out), ov = stage_linear(st, h.vad_dense);
+  const StagedModel &sm = *m->staged;
   DeviceModel d;
   d.device = device;
   ON_DEVICE(device);
-  HIP_OK(hipMalloc(&d.mem, st.bytes.size()));
-  HIP_OK(hipMemcpy(d.mem, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&d.mem, sm.st.bytes.size()));
+  HIP_OK(hipMemcpy(d.mem, sm.st.bytes.data(), sm.st.bytes.size(), hipMemcpyHostToDevice));
   const uint8_t *base = static_cast<const uint8_t *>(d.mem);
-  d.dev.conv1 = resolve_linear(base, oc1, h.conv1);
-  d.dev.conv2 = resolve_linear(base, oc2, h.conv2);
-  for (int k = 0; k < 3; k++) {
-    d.dev.gru_in[k] = resolve_linear(base, ogi[k], h.gru_in[k]);
-    d.dev.gru_rec[k] = resolve_linear(base, ogr[k], h.gru_rec[k]);
-  }
-  d.dev.dense_out = resolve_linear(base, od, h.dense_out);
-  d.dev.vad_dense = resolve_linear(base, ov, h.vad_dense);
+  RnLinearDev *dst[10] = {&d.dev.conv1, &d.dev.conv2, &d.dev.gru_in[0], &d.dev.gru_rec[0], &d.dev.gru_in[1], &d.dev.gru_rec[1],
+                          &d.dev.gru_in[2], &d.dev.gru_rec[2], &d.dev.dense_out, &d.dev.vad_dense};
+  for (int i = 0; i < 10; i++) *dst[i] = resolve_linear(base, sm.off[i], sm.lin[i]);
   m->dev.push_back(d);
   out = d.dev;
   return 0;
@@ -1080,11 +1177,40 @@ extern "C" long rnnoise_model_weight_bytes(RNNModel *model) {
   if (!model) return -1;
   std::lock_guard<std::mutex> lk(model->mu);
   if (model_parse_locked(model)) return -1;
-  const HostModel &h = model->host;
-  long w = linear_weight_bytes(h.conv1) + linear_weight_bytes(h.conv2) + linear_weight_bytes(h.dense_out) +
-           linear_weight_bytes(h.vad_dense);
-  for (int k = 0; k < 3; k++) w += linear_weight_bytes(h.gru_in[k]) + linear_weight_bytes(h.gru_rec[k]);
-  return w;
+  return model->weight_bytes;
+}
+
+// Serialise `model` (from a "DNNw" blob or from a pack) as an "RNPK" pack.  Returns the pack's size in bytes; the bytes
+// are written only if cap is large enough (call with out == NULL to size the buffer).  -1 on a rejected model.  Host only.
+extern "C" long rnnoise_amd_model_pack(RNNModel *model, void *out, long cap) {
+  if (!model) return -1;
+  std::lock_guard<std::mutex> lk(model->mu);
+  if (model_parse_locked(model)) return -1;
+  if (!model->staged) {
+    model->staged = new StagedModel();
+    stage_model(model->host, *model->staged);
+  }
+  const StagedModel &sm = *model->staged;
+  const long total = (long)(sizeof(PackHeader) + sm.st.bytes.size());
+  if (!out || cap < total) return total;
+  PackHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "RNPK", 4);
+  h.version = RN_PACK_VERSION;
+  memcpy(h.dims, kPackDims, sizeof kPackDims);
+  h.weight_bytes = model->weight_bytes;
+  h.payload_bytes = sm.st.bytes.size();
+  for (int i = 0; i < 10; i++) {
+    const DevLinearOffsets &o = sm.off[i];
+    PackLayer &l = h.layers[i];
+    l.bias = o.bias; l.fw = o.fw; l.scale = o.scale; l.diag = o.diag; l.w = o.w; l.wmf = o.wmf; l.rowsum = o.rowsum;
+    l.grp = o.grp; l.cols = o.cols;
+    l.has_fw = o.has_fw; l.has_diag = o.has_diag; l.has_cols = o.has_cols; l.is_int8 = o.is_int8;
+    l.nin = sm.lin[i].nin; l.nout = sm.lin[i].nout; l.nblocks = sm.lin[i].nblocks;
+  }
+  memcpy(out, &h, sizeof h);
+  memcpy(static_cast<uint8_t *>(out) + sizeof h, sm.st.bytes.data(), sm.st.bytes.size());
+  return total;
 }
 
 extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch) {
@@ -1360,6 +1486,7 @@ extern "C" void rnnoise_model_free(RNNModel *model) {
     hipFree(d.mem);
   }
   if (model->file) fclose(model->file);
+  delete model->staged;
   free(model->blob);
   delete model;
 }

@@ -13,8 +13,34 @@ from . import blob as rblob
 from . import capi
 
 
+_OPS = {}          # handle -> RNNoiseOp: what torch.ops.rnnoise_amd.process resolves its integer argument to
+_registered = False
+
+
+def register_torch_op():
+    """Registers `torch.ops.rnnoise_amd.process(pcm, handle) -> (out, vad, gains)` (torch.library custom op, forward only).
+    `handle` is RNNoiseOp.handle: the op is stateful per stream batch, like the C API it binds, and the state lives in the
+    library, not in tensors.  A fake (meta) implementation gives shapes to tracing / torch.compile."""
+    global _registered
+    if _registered:
+        return
+    import torch
+
+    @torch.library.custom_op("rnnoise_amd::process", mutates_args=())
+    def process(pcm: torch.Tensor, handle: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return _OPS[handle]._run(pcm)
+
+    @process.register_fake
+    def _(pcm, handle):
+        T, N = pcm.shape[0], pcm.shape[1]
+        return torch.empty_like(pcm), pcm.new_empty((T, N)), pcm.new_empty((T, N, capi.NB_BANDS))
+
+    _registered = True
+
+
 class RNNoiseOp:
-    """N concurrent streams; call with a (T, N, 480) float32 CUDA tensor of int16-scaled PCM."""
+    """N concurrent streams; call with a (T, N, 480) float32 CUDA tensor of int16-scaled PCM.  The same object is
+    reachable as the registered op: torch.ops.rnnoise_amd.process(pcm, op.handle)."""
 
     def __init__(self, model_blob: bytes, n_streams: int, device: int = 0, nn_path: str = "mfma"):
         import torch
@@ -25,8 +51,19 @@ class RNNoiseOp:
         if nn_path == "mfma":
             self.batch.set_nn_path(1)
         self.n = n_streams
+        register_torch_op()
+        self.handle = id(self)
+        _OPS[self.handle] = self
+
+    def close(self):
+        _OPS.pop(self.handle, None)
+        self.batch.close()
+        self.model.close()
 
     def __call__(self, pcm):
+        return self.torch.ops.rnnoise_amd.process(pcm, self.handle)
+
+    def _run(self, pcm):
         torch = self.torch
         assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.shape[1:] == (self.n, capi.FRAME)
         pcm = pcm.contiguous()

@@ -69,3 +69,56 @@ def test_synthetic_models_on_gpu(density, path):
         assert_bits_equal(gains[:, i], want["gains"], "gains")
         assert_bits_equal(vad[:, i], want["vad"], "vad")
         assert_bits_equal(out[:, i], want["out"], "pcm")
+
+
+# ---- "RNPK": the GPU-native packed model (include/rnnoise_amd.h rnnoise_amd_model_pack) --------------
+def test_pack_round_trip_and_header(blob_default, blob_little, tmp_path):
+    from rnnoise_amd import capi
+    for b in (blob_default, blob_little):
+        p = rb.pack(b)
+        h = rb.read_pack_header(p)
+        assert p[:4] == b"RNPK" and h["version"] == 1 and h["dims"] == [195, 128, 384, 384, 384, 1536, 32, 64]
+        assert h["weight_bytes"] == capi.Model(b).weight_bytes and h["payload_bytes"] == len(p) - h["header_bytes"]
+        assert [l["name"] for l in h["layers"]] == rb.PACK_LAYERS
+        m = capi.Model(p)                       # rnnoise_model_from_buffer accepts the pack
+        assert m.weight_bytes == h["weight_bytes"]
+        assert m.pack() == p                    # packing a packed model reproduces it byte for byte
+    # the int8 payload of a layer is the blob's own block stream, untouched
+    rec = rb.read_blob(blob_default)
+    h = rb.read_pack_header(rb.pack(blob_default))
+    l = h["layers"][2]
+    w = np.frombuffer(rb.pack(blob_default), np.int8, 32 * l["nblocks"], h["header_bytes"] + l["offsets"]["w"])
+    assert np.array_equal(w, rec["gru1_input_weights_int8"])
+    # command-line form + loading through the file entry point
+    (tmp_path / "m.blob").write_bytes(blob_default)
+    rb.main(["pack", str(tmp_path / "m.blob"), str(tmp_path / "m.rnpk")])
+    assert (tmp_path / "m.rnpk").read_bytes() == rb.pack(blob_default)
+    L = capi.lib()
+    mh = L.rnnoise_model_from_filename(str(tmp_path / "m.rnpk").encode())
+    assert mh and L.rnnoise_model_weight_bytes(mh) == h["weight_bytes"]
+    L.rnnoise_model_free(mh)
+
+
+def test_corrupt_packs_are_rejected(blob_default):
+    import struct
+    from rnnoise_amd import capi
+    good = bytearray(rb.pack(blob_default))
+    h = rb.read_pack_header(bytes(good))
+
+    def rejected(b):
+        try:
+            capi.Model(bytes(b)).weight_bytes
+        except ValueError:
+            return True
+        return False
+
+    assert not rejected(good)
+    bad = bytearray(good); struct.pack_into("<I", bad, 4, 2); assert rejected(bad)                      # unknown version
+    bad = bytearray(good); struct.pack_into("<I", bad, 8 + 4 * 4, 512); assert rejected(bad)            # other GRU size
+    assert rejected(good[:-1]) and rejected(good + b"\\0")                                               # payload size mismatch
+    assert rejected(good[:200])                                                                         # truncated header
+    lay = 56 + 2 * 104                                                                                  # gru1_input record
+    bad = bytearray(good); struct.pack_into("<Q", bad, lay + 5 * 8, h["payload_bytes"] - 16); assert rejected(bad)   # MFMA image runs off the end
+    bad = bytearray(good); struct.pack_into("<i", bad, lay + 9 * 8 + 16 + 8, 10 ** 6); assert rejected(bad)          # absurd block count
+    cols = h["header_bytes"] + h["layers"][2]["offsets"]["cols"]
+    bad = bytearray(good); struct.pack_into("<H", bad, cols, 382); assert rejected(bad)                 # column index past the input
