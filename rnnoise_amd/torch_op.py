@@ -26,8 +26,9 @@ def register_torch_op():
         return
     import torch
 
-    @torch.library.custom_op("rnnoise_amd::process", mutates_args=())
-    def process(pcm: torch.Tensor, handle: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    # (explicit schema: this module uses postponed annotations, which infer_schema cannot resolve for a local import)
+    @torch.library.custom_op("rnnoise_amd::process", mutates_args=(), schema="(Tensor pcm, int handle) -> (Tensor, Tensor, Tensor)")
+    def process(pcm, handle):
         return _OPS[handle]._run(pcm)
 
     @process.register_fake
