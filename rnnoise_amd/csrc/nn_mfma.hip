@@ -25,8 +25,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define NWAVES 8       // 2 waves per SIMD: one wave's weight loads / epilogue overlap the other's MFMAs
 #define NTHREADS (64 * NWAVES)
 #define KT 6           // 384 / 64 k-tiles of every int8 layer
-#define CHUNK 128      // inputs per staged chunk of the dense_out / vad chains
-#define CH_STRIDE 132  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
+#define CHUNK 256      // inputs per staged chunk of the dense_out / vad chains
+#define CH_STRIDE 260  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
 
 // ---- x86-profile activations (same arithmetic as nn_kernels.hip; LUT staged in LDS) ----
 __device__ __forceinline__ float rcp_x86(float x, const uint32_t *lut) {
@@ -73,6 +73,7 @@ __device__ __forceinline__ int frag_off(int n, int k) { return (((k >> 6) * 64 +
 
 struct MfmaLds {
   uint32_t lut[2048];             // rcpps table
+  float vadw[RN_CAT];             // vad_dense weights: the lane = stream chain of wave 2 must not wait for L2 at every step
   union {
     struct {
       float tmp1[TS][197];          // conv1 input [t-2|t-1|t], padded row
@@ -129,6 +130,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   } while (0)
 
   for (int i = tid; i < 2048; i += NTHREADS) L.lut[i] = tb.rcp_lut[i];
+  for (int i = tid; i < RN_CAT; i += NTHREADS) L.vadw[i] = m.vad_dense.fw[i];
   // ---- conv1 input: [conv1_state(130) | features(65) | 0] per stream ----
   for (int e = tid; e < TS * 196; e += NTHREADS) {
     const int q = e / 196, k = e - q * 196, s = (s0 + q < N) ? s0 + q : N - 1;
@@ -242,50 +244,62 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   // chunks of 128 inputs by the whole workgroup (one coalesced 16-byte load per thread and chunk, issued
   // a full chunk ahead and parked in a register), because fetched straight from the per-stream rows every
   // chain step costs 16 scattered L1 accesses -- and the vector L1 is what this kernel saturates first.
-  // The dense weights stay in L2 (64-byte rows, 8 steps ahead).
+  // Measured with the phase taps at 65,536 streams: what paced this phase was the lane = stream VAD chain waiting for its
+  // weights in L2 at every step (77k -> 54k clocks per tile with the weights in LDS), not the MFMA chain's weights.
+  // Dead ends (this round): running the chains segment by segment inside the GRU phases (the tile loop then spills at
+  // 128 VGPRs: K2 1.00 -> 1.14-1.28 ms); one 384-input chunk per barrier (172 VGPRs or spills: 1.13 ms).
   {
-    const int pq = tid >> 5, pc = (tid & 31) << 2;              // producer role: stream pq, floats pc..pc+3 of a chunk
+    const int pq = tid >> 5, pc = (tid & 31) << 2;              // producer role: stream pq, floats pc + 128 j .. +3 of a chunk, j = 0, 1
     const int ps = (s0 + pq < N) ? s0 + pq : N - 1;
     auto chunk_src = [&](int c) {                                // chunk c = inputs 128c .. 128c+127 of cat
-      const int seg = c / 3, k0 = (c - 3 * seg) * CHUNK;
-      return reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * g.n_stride * RN_GRU) +
-                                           (size_t)ps * RN_GRU + k0 + pc);
+      // half-chunk h = 2c + j covers inputs 128 h .. 128 h + 127 of cat: segment h / 3, offset 128 (h % 3)
+      return [=](int j) {
+        const int h = 2 * c + j, seg = h / 3, k0 = (h - 3 * seg) * 128;
+        return *reinterpret_cast<const v4f *>((seg == 0 ? g.nn_act : g.gru_state + (size_t)(seg - 1) * g.n_stride * RN_GRU) +
+                                              (size_t)ps * RN_GRU + k0 + pc);
+      };
     };
     constexpr int NCH = 4 * RN_GRU / CHUNK;  // 12
-    v4f park = *chunk_src(0);
-    *reinterpret_cast<v4f *>(&L.stage[0][pq][pc]) = park;  // xq / hq / tmp1 are dead: the last GRU barrier is behind us
-    park = *chunk_src(1);
+    v4f park[2] = {chunk_src(0)(0), chunk_src(0)(1)};
+    *reinterpret_cast<v4f *>(&L.stage[0][pq][pc]) = park[0];  // xq / hq / tmp1 are dead: the last GRU barrier is behind us
+    *reinterpret_cast<v4f *>(&L.stage[0][pq][pc + 128]) = park[1];
+    park[0] = chunk_src(1)(0);
+    park[1] = chunk_src(1)(1);
     v4f dacc = {0, 0, 0, 0};
     float vacc = 0;
-    const float *fw = m.dense_out.fw + (size_t)gq * RN_NB_BANDS + 16 * (wave & 1) + n;  // element k = 4t+gq, t global
-    float ca[8];
+    // dense_out weights: the MFMA-ordered copy (shim.cpp: stage_linear) -- 16 bytes = this lane's operands of four
+    // consecutive steps, WDEPTH loads (4 x WDEPTH steps, > 1000 cycles of chain) in flight
+    constexpr int WDEPTH = 8, NW4 = RN_CAT / 16;  // 96 groups of four steps
+    static_assert((CHUNK / 16) % WDEPTH == 0, "a chunk is a whole number of weight-buffer rounds");
+    const v4f *wq = reinterpret_cast<const v4f *>(m.dense_out.fwm) + (size_t)(wave & 1) * NW4 * 64 + lane;
+    v4f wbuf[WDEPTH];
     if (wave < 2) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) ca[u] = fw[(size_t)(4 * u) * RN_NB_BANDS];
+      for (int u = 0; u < WDEPTH; u++) wbuf[u] = wq[u * 64];
     }
     __syncthreads();
     for (int c = 0; c < NCH; c++) {
-      if (c + 1 < NCH) *reinterpret_cast<v4f *>(&L.stage[(c + 1) & 1][pq][pc]) = park;
-      if (c + 2 < NCH) park = *chunk_src(c + 2);
+      if (c + 1 < NCH) {
+        *reinterpret_cast<v4f *>(&L.stage[(c + 1) & 1][pq][pc]) = park[0];
+        *reinterpret_cast<v4f *>(&L.stage[(c + 1) & 1][pq][pc + 128]) = park[1];
+      }
+      if (c + 2 < NCH) {
+        park[0] = chunk_src(c + 2)(0);
+        park[1] = chunk_src(c + 2)(1);
+      }
       const float(*sx)[CH_STRIDE] = L.stage[c & 1];
-      if (wave < 2) {  // 32 MFMA steps: t = 32c + tt, k = 4t + gq
+      if (wave < 2) {  // 64 MFMA steps: k = 256c + 16*t4 + 4e + gq
         const float *bx = &sx[n][gq];
-        for (int t0 = 0; t0 < CHUNK / 4; t0 += 8) {
-          const int t = (CHUNK / 4) * c + t0;
-          const int tn = (t + 8 < 4 * RN_GRU / 4) ? t + 8 : t;
-          float na[8], cb[8];
+#pragma unroll 8
+        for (int t4 = 0; t4 < CHUNK / 16; t4++) {
+          const int gidx = (CHUNK / 16) * c + t4;
+          const v4f a = wbuf[t4 % WDEPTH];  // slot t4 % WDEPTH holds group gidx
+          if (gidx + WDEPTH < NW4) wbuf[t4 % WDEPTH] = wq[(size_t)(gidx + WDEPTH) * 64];
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            na[u] = fw[(size_t)(4 * (tn + u)) * RN_NB_BANDS];
-            cb[u] = bx[4 * (t0 + u)];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[u], cb[u], dacc, 0, 0, 0);
-#pragma unroll
-          for (int u = 0; u < 8; u++) ca[u] = na[u];
+          for (int e = 0; e < 4; e++) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bx[16 * t4 + 4 * e], dacc, 0, 0, 0);
         }
       } else if (wave == 2 && lane < TS) {  // unfused mul-then-add, src/vec_avx.h:732-736
-        const v4f *w = reinterpret_cast<const v4f *>(m.vad_dense.fw + CHUNK * c);
+        const v4f *w = reinterpret_cast<const v4f *>(L.vadw + CHUNK * c);
         const v4f *x = reinterpret_cast<const v4f *>(sx[lane]);
 #pragma unroll 4
         for (int j = 0; j < CHUNK / 4; j++) {
@@ -314,7 +328,7 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                         hipEvent_t e0, hipEvent_t e1) {
-  if (!m->conv2.wmf || !g->nn_act) return hipErrorNotSupported;
+  if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm) return hipErrorNotSupported;
   RN_LAUNCH(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }

@@ -45,6 +45,7 @@ struct RnTablesDev {
 struct RnLinearDev {
   const float *bias;      // float layers: bias; int8 layers: subias (x86 profile, nnet_arch.h:145-147)
   const float *fw;        // float weights, column-major W[j*N + i]
+  const float *fwm;       // the same in v_mfma_f32_16x16x4_f32 operand order [row tile][step/4][lane][step%4] (nout % 16 == 0), or null
   const float *scale;     // per-output scale (already /127, c_export/common.py:248)
   const float *diag;      // recurrent diagonal [3*M] or null
   const int8_t *w;        // int8 blocks, 32 bytes each = [8 rows][4 cols]

@@ -216,7 +216,7 @@ struct Staging {
 };
 
 struct DevLinearOffsets {
-  size_t bias = 0, fw = 0, scale = 0, diag = 0, w = 0, wmf = 0, rowsum = 0, grp = 0, cols = 0;
+  size_t bias = 0, fw = 0, scale = 0, diag = 0, w = 0, wmf = 0, rowsum = 0, grp = 0, cols = 0;  // (float layers: wmf = MFMA-ordered copy)
   bool has_fw = false, has_diag = false, has_cols = false, is_int8 = false;
 };
 
@@ -227,6 +227,20 @@ DevLinearOffsets stage_linear(Staging &st, const HostLinear &l) {
     o.bias = st.add(l.bias, 4 * l.nout);
     o.fw = st.add(l.fw, 4L * l.nin * l.nout);
     o.has_fw = true;
+    if (l.nout % 16 == 0) {
+      // copy in the operand order of v_mfma_f32_16x16x4_f32 chains (nn_mfma.hip): [row tile][step / 4][lane][step % 4], the
+      // element of step t for lane l being W[k = 4t + (l >> 4)][16 rt + (l & 15)] (0 past the last input): a lane's weights of
+      // four consecutive steps are one 16-byte load, a wave's are 1 KB contiguous
+      const int steps4 = (l.nin + 15) / 16, RT = l.nout / 16;
+      std::vector<float> fm((size_t)RT * steps4 * 64 * 4, 0.f);
+      for (int rt = 0; rt < RT; rt++)
+        for (int t = 0; t < 4 * steps4; t++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int k = 4 * t + (lane >> 4);
+            if (k < l.nin) fm[(((size_t)rt * steps4 + t / 4) * 64 + lane) * 4 + (t & 3)] = l.fw[(size_t)k * l.nout + 16 * rt + (lane & 15)];
+          }
+      o.wmf = st.add(fm.data(), 4 * fm.size());
+    }
     return o;
   }
   o.bias = st.add(l.subias, 4 * l.nout);  // x86 profile adds subias to int8 layers
@@ -282,6 +296,7 @@ RnLinearDev resolve_linear(const uint8_t *base, const DevLinearOffsets &o, const
   d.nout = l.nout;
   d.bias = reinterpret_cast<const float *>(base + o.bias);
   if (o.has_fw) d.fw = reinterpret_cast<const float *>(base + o.fw);
+  if (o.has_fw && o.wmf) d.fwm = reinterpret_cast<const float *>(base + o.wmf);
   if (o.is_int8) {
     d.scale = reinterpret_cast<const float *>(base + o.scale);
     d.w = reinterpret_cast<const int8_t *>(base + o.w);
@@ -539,7 +554,7 @@ struct PackHeader {
   uint64_t payload_bytes;
   PackLayer layers[10]; // conv1, conv2, gru1..3 input, gru1..3 recurrent (interleaved in, rec), dense_out, vad_dense
 };
-static const uint32_t RN_PACK_VERSION = 1;
+static const uint32_t RN_PACK_VERSION = 2;  // 2: float layers carry an MFMA-ordered copy
 static const uint32_t kPackDims[8] = {RN_CONV1_K, RN_CONV1_OUT, RN_CONV2_K, RN_CONV2_OUT, RN_GRU, RN_CAT, RN_NB_BANDS, 64};
 
 struct StagedModel {
@@ -595,7 +610,7 @@ bool unpack_model(const void *p, int len, StagedModel &sm, long &weight_bytes) {
         if (grp[gidx + 1] < grp[gidx]) return false;
       for (int b = 0; b < l.nblocks; b++)
         if (cols[b] + 3 >= l.nin || (cols[b] & 3)) return false;
-    } else if (!l.has_fw || !fits(l.fw, 4 * no * ni)) {
+    } else if (!l.has_fw || !fits(l.fw, 4 * no * ni) || (no % 16 == 0 && !fits(l.wmf, 4 * no * ((ni + 15) / 16) * 16))) {
       return false;
     }
     DevLinearOffsets &o = sm.off[i];

@@ -77,7 +77,7 @@ def test_pack_round_trip_and_header(blob_default, blob_little, tmp_path):
     for b in (blob_default, blob_little):
         p = rb.pack(b)
         h = rb.read_pack_header(p)
-        assert p[:4] == b"RNPK" and h["version"] == 1 and h["dims"] == [195, 128, 384, 384, 384, 1536, 32, 64]
+        assert p[:4] == b"RNPK" and h["version"] == 2 and h["dims"] == [195, 128, 384, 384, 384, 1536, 32, 64]
         assert h["weight_bytes"] == capi.Model(b).weight_bytes and h["payload_bytes"] == len(p) - h["header_bytes"]
         assert [l["name"] for l in h["layers"]] == rb.PACK_LAYERS
         m = capi.Model(p)                       # rnnoise_model_from_buffer accepts the pack
@@ -113,7 +113,7 @@ def test_corrupt_packs_are_rejected(blob_default):
         return False
 
     assert not rejected(good)
-    bad = bytearray(good); struct.pack_into("<I", bad, 4, 2); assert rejected(bad)                      # unknown version
+    bad = bytearray(good); struct.pack_into("<I", bad, 4, 1); assert rejected(bad)                      # unknown version
     bad = bytearray(good); struct.pack_into("<I", bad, 8 + 4 * 4, 512); assert rejected(bad)            # other GRU size
     assert rejected(good[:-1]) and rejected(good + b"\\0")                                               # payload size mismatch
     assert rejected(good[:200])                                                                         # truncated header
