@@ -105,13 +105,14 @@ def synth_pcm_torch(torch, n_streams: int, n_frames: int, device, seed_base: int
     return out
 
 
-def pmc_record(kernel: str, n_streams: int):
+def pmc_record(kernel: str, n_streams: int, model: str = "default"):
     """Per-kernel counters from the committed PMC passes (profiles/pmc_by_streams.json, written by
     tools/make_profile_tables.py from rocprofv3 --pmc runs: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU in separate passes,
     gfx950 x2 read correction): the set measured nearest (in octaves) to this batch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_by_streams.json")) as f:
-            sets = json.load(f)["by_streams"]
+            allsets = json.load(f)
+        sets = allsets.get(model) if model != "default" and allsets.get(model) else allsets["by_streams"]
         k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]
         return k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", ""))
     except Exception:
@@ -323,6 +324,18 @@ def bench_rank(a) -> dict | None:
         barrier()
         times.append(time.perf_counter() - t0)
     kms = batch.kernel_ms()
+    # the same K steps once more with every kernel on ONE stream: stand-alone kernel durations (in the pipelined schedule
+    # the kernels of neighbouring frames share the machine, which stretches each one's own duration)
+    kms_alone = None
+    if not stub and not a.host_io:
+        old = batch.set_schedule(9)
+        run(Wm + R * K, K)
+        sync()
+        batch.kernel_ms()
+        run(Wm + (R + 1) * K, K)
+        sync()
+        kms_alone = batch.kernel_ms()
+        batch.set_schedule(old)
     batch.enable_timing(False)
     times = aggregate_times(times, dist, dev)  # element-wise MAX over ranks
     frames_per_rep = float(N * K * world)
@@ -340,7 +353,7 @@ def bench_rank(a) -> dict | None:
         if dom == "analysis" and N < 6144:
             kname = "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
         ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        pmc = pmc_record(kname, N) or {}
+        pmc = pmc_record(kname, N, a.model) or {}
         traffic = int(pmc["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pmc else None
         line = {
             "metric": METRIC if not stub else "LAUNCHER SELF-TEST (stub batch, no GPU work)",
@@ -367,9 +380,29 @@ def bench_rank(a) -> dict | None:
                                 "definition": "frames/s x W / (n_gpus x 8.0e12 B/s), north_star / SURVEY 8d; weights are "
                                               "L2-served, so this normalised figure may exceed 1"},
         }
+        if kms_alone:
+            da = max(kinds, key=lambda k: kms_alone[k])
+            na = KERNEL_OF[da] if (da != "network" or a.nn == "mfma") else "rn_nn_vector_kernel"
+            if da == "analysis" and N < 6144:
+                na = "rn_analysis_single_kernel"
+            pa = pmc_record(na, N, a.model) or {}
+            aa = per_launch[da] / (kms_alone[da] * 1e-3) / 1e9
+            line["roofline_standalone"] = {
+                "bound": "hbm", "kernel": na, "achieved": round(aa, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(aa * 1e9 / HBM_PEAK, 5),
+                "traffic": int(pa["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pa else None,
+                "algorithmic_bytes_per_launch": per_launch[da], "kernel_ms": {k: round(kms_alone[k], 4) for k in kinds},
+                "note": "same workload, every kernel on one stream (no overlap between kernels), outside the timed region"}
+            if "valu_per_wave" in pa:
+                ti = pa["valu_per_wave"] * waves_per_launch(da, N) * pa.get("valu_cycles_per_inst", 4) / N_SIMD / CLOCK_HZ
+                line["roofline_standalone"]["valu_issue_frac"] = round(ti / (kms_alone[da] * 1e-3), 4)
+                line["roofline_standalone"]["valu_note"] = (f"{pa['valu_per_wave']} VALU instructions per wave x "
+                                                           f"{pa.get('valu_cycles_per_inst', 4)} clk (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, measured) "
+                                                           "over 1024 SIMDs at 2.4 GHz")
         if "valu_per_wave" in pmc and kms[dom] > 0:
-            # VALU-issue bound: instructions x 2 clk (wave64 on a SIMD-32) spread over 1024 SIMDs at 2.4 GHz
-            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * 2 / N_SIMD / CLOCK_HZ
+            # VALU-issue bound: instructions x the measured issue cost (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU ~ 4 clk per wave64
+            # instruction on this kernel mix, not the 2 clk of a pure f32 stream) spread over 1024 SIMDs at 2.4 GHz
+            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * pmc.get("valu_cycles_per_inst", 4) / N_SIMD / CLOCK_HZ
             line["roofline_valu"] = {"bound": "valu-issue", "kernel": kname, "valu_insts_per_wave": pmc["valu_per_wave"],
                                      "waves": waves_per_launch(dom, N), "issue_bound_ms": round(1e3 * t_issue, 4),
                                      "frac": round(t_issue / (kms[dom] * 1e-3), 4), "source": pmc.get("source", "profiles/")}

@@ -60,6 +60,12 @@ RNNOISE_EXPORT int rnnoise_batch_import_state(RNNoiseBatch *b, int stream, const
  * Returns the previous value, or -1 if unsupported. */
 RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);
 
+/* Stream schedule of multi-frame rnnoise_batch_process_device calls: 0 = default (three-stream frame pipeline: high-pass
+ * up to two frames ahead, analysis of frame t+1 beside network + synthesis of frame t), 9 = every kernel on the caller's
+ * stream (stand-alone kernel timings), 1 = only the high-pass on a side stream.  Same bits in every mode.
+ * Returns the previous value, or -1. */
+RNNOISE_EXPORT int rnnoise_batch_set_schedule(RNNoiseBatch *b, int schedule);
+
 /* Weight bytes one frame touches (SURVEY 8d "W"): the numerator of the HBM-roofline
  * fraction reported by bench.py. */
 RNNOISE_EXPORT long rnnoise_model_weight_bytes(RNNModel *model);

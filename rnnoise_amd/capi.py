@@ -32,7 +32,7 @@ EXPORTS = [
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
-    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft", "rnnoise_amd_model_pack",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft", "rnnoise_amd_model_pack", "rnnoise_batch_set_schedule",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         L.rnnoise_batch_export_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_import_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_set_nn_path.argtypes = [vp, C.c_int]
+        L.rnnoise_batch_set_schedule.argtypes = [vp, C.c_int]
         L.rnnoise_amd_model_pack.restype = C.c_long
         L.rnnoise_amd_model_pack.argtypes = [vp, vp, C.c_long]
         L.rnnoise_model_weight_bytes.restype = C.c_long
@@ -165,6 +166,12 @@ class Batch:
         r = lib().rnnoise_batch_set_nn_path(self.h, path)
         if r < 0:
             raise RuntimeError(f"network path {path} unsupported")
+        return r
+
+    def set_schedule(self, schedule: int) -> int:
+        r = lib().rnnoise_batch_set_schedule(self.h, schedule)
+        if r < 0:
+            raise RuntimeError(f"schedule {schedule} unsupported")
         return r
 
     def process(self, pcm: np.ndarray, want_gains: bool = True):

@@ -332,10 +332,6 @@ __device__ __forceinline__ void energy_sweeps_run(float *rsq, float *D, const fl
     b = bn;
   }
 }
-__device__ __forceinline__ void energy_sweeps_clamp(float *rsq, int lane) {
-  for (int i = 1 + lane; i <= 384; i += WAVE) rsq[479 + i] = fmaxf(0.f, rsq[479 + i]);  // MAX32(0, yy)
-}
-
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
   return (float)(xy / sqrt((double)(1 + xx * yy)));
 }
@@ -389,6 +385,40 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
   return s;
 }
 
+// chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
+// For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
+// dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
+__device__ __forceinline__ float chain_dot8_y2(const float *x, const float *y2, int n) {
+  float s = 0.f;
+  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
+  float2 ya[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) ya[k] = *reinterpret_cast<const float2 *>(y2 + 2 * k);
+  for (int i = 0; i < n; i += 8) {
+    const int nx = (i + 8 < n) ? i + 8 : i;
+    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
+    float2 yn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) yn[k] = *reinterpret_cast<const float2 *>(y2 + nx + 2 * k);
+    float p0 = xa.x * ya[0].x, p1 = xa.y * ya[0].y, p2 = xa.z * ya[1].x, p3 = xa.w * ya[1].y;
+    float p4 = xb.x * ya[2].x, p5 = xb.y * ya[2].y, p6 = xb.z * ya[3].x, p7 = xb.w * ya[3].y;
+    OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
+    s = s + p0;
+    s = s + p1;
+    s = s + p2;
+    s = s + p3;
+    s = s + p4;
+    s = s + p5;
+    s = s + p6;
+    s = s + p7;
+    xa = xc;
+    xb = xd;
+#pragma unroll
+    for (int k = 0; k < 4; k++) ya[k] = yn[k];
+  }
+  return s;
+}
+
 // One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared
 // (float offsets, the SCR_* constants below):
 //   FFT phases   : F = [0,2160) (960 complex, padded layout); the band products Q live in [1084,1948),
@@ -433,7 +463,7 @@ __device__ __forceinline__ v2f chain_dot8_x2(const float *x, const v2f *z, int n
 }
 
 struct AnalysisLds {
-  float a[2560];
+  float a[2368];  // 9,472 B: three of these workgroups (4 arenas each) leave 50 KB of a CU's LDS to a network-kernel tile
 };
 #define SCR_XLP 0
 #define SCR_SQ 864    // [864]  fine search: reversed squares of xlp, later yy_lookup
@@ -443,9 +473,12 @@ struct AnalysisLds {
 #define SCR_D 1732    // [-1..295] fine search: Syy increments, then Syy itself (16-byte aligned)
 #define SCR_XC 2028   // [296]  xcorr[] of pitch_search
 #define SCR_ZERO 2324 // [4]
-#define SCR_DOTS 2120 // [64]
+#define SCR_DOTS 2120 // [64]  doubling dots (behind yy_lookup, over the dead fine xcorr)
+#define SCR_YYL 1732  // [385] yy_lookup after the fine search (over the dead Syy / fine xcorr areas)
+#define SCR_XS 864    // [864] x_lp shifted by one sample, for the 8-byte reads of the doubling dots (over the dead squares)
 #define SCR_Q 1084    // [864]  band products (above the padded bins 0..480 = floats [0,1082))
-#define SCR_MISC 2392 // sums[40] | Ex[32] | Ep[32] | Exp[32] | Ly[32]
+#define SCR_EX 2336   // [32]  band energies of X: the one vector that lives from the first transform to the features
+#define SCR_MISC 1952 // sums[40] | Ep[32] | Exp[32] | Ly[32]: transform phases only (behind the band products)
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
@@ -462,7 +495,7 @@ struct AnalysisLds {
 // without issuing anything.  Every chain is still one lane's serial sum in the reference order.
 // ---------------------------------------------------------------------------------------------
 #define K1_SPW 4       // streams (= waves) per workgroup of the inference kernels: 12 fine-search lanes x 4 <= 64
-#define K1_MAIL 8      // floats of mailbox per stream behind the arenas: values handed between a stream's wave and wave 0
+#define SCR_MAIL 2328  // [8] mailbox of the stream inside its own arena: values handed between a stream's wave and wave 0
 #define MAIL_SYY0C 0   //   start energy of the coarse find_best_pitch
 #define MAIL_BP0 1     //   coarse best lags (int bits)
 #define MAIL_BP1 2
@@ -474,10 +507,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw);
-  float *mailbox = reinterpret_cast<float *>(smem_raw + SPW * sizeof(AnalysisLds));
   const int wave = SPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, lane = threadIdx.x & (WAVE - 1);
   AnalysisLds &L = arenas[wave];
-  float *mail = mailbox + wave * K1_MAIL;
+  float *mail = L.a + SCR_MAIL;
   // a tail workgroup's surplus waves redo the last stream without storing anything: they still meet every barrier
   const int s_raw = blockIdx.x * SPW + wave;
   const bool wr = s_raw < g.n_streams;
@@ -490,7 +522,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   } while (0)
   float *scr = L.a;
   float *xlp = scr + SCR_XLP, *Qs = scr + SCR_Q;
-  float *sums = scr + SCR_MISC, *Ex = sums + 40, *Ep = Ex + 32, *Exp = Ep + 32, *Ly = Exp + 32;
+  float *sums = scr + SCR_MISC, *Ex = scr + SCR_EX, *Ep = sums + 40, *Exp = Ep + 32, *Ly = Exp + 32;
   float *dbg = (g.debug && wr) ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
   const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
@@ -617,7 +649,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   WG_SYNC();
   if (wave == 0) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
     const int gi = lane < SPW ? lane : 0;
-    fbp_sweep(arenas[gi].a + SCR_SYY, 147, mailbox[gi * K1_MAIL + MAIL_SYY0C], lane < SPW);
+    fbp_sweep(arenas[gi].a + SCR_SYY, 147, arenas[gi].a[SCR_MAIL + MAIL_SYY0C], lane < SPW);
   }
   WG_SYNC();
   best_pitch_select(xc, scr + SCR_SYY, 147, bp0, bp1, lane);
@@ -642,7 +674,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const int gq = lane / 12, r = lane - 12 * gq;
       const bool on = gq < SPW;
       const int gi = on ? gq : 0;
-      float *xlp_g = arenas[gi].a + SCR_XLP, *xc_g = arenas[gi].a + SCR_XC, *mail_g = mailbox + gi * K1_MAIL;
+      float *xlp_g = arenas[gi].a + SCR_XLP, *xc_g = arenas[gi].a + SCR_XC, *mail_g = arenas[gi].a + SCR_MAIL;
       const int b0 = __float_as_int(mail_g[MAIL_BP0]), b1 = __float_as_int(mail_g[MAIL_BP1]);
       const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
       const bool lag = on && r < 10 && c >= 0 && c < 294;
@@ -662,16 +694,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const bool on = gq < SPW;
       const int gi = on ? gq : 0;
       float *a = arenas[gi].a;
-      const float *mail_g = mailbox + gi * K1_MAIL;
+      const float *mail_g = arenas[gi].a + SCR_MAIL;
       energy_sweeps_run(a + SCR_SQ, a + SCR_D, a + SCR_ZERO, mail_g[MAIL_SYY0F], mail_g[MAIL_XX], role, on);
     }
     CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps of the whole workgroup (wave 0's view)
   }
   WG_SYNC();
   const float xx = mail[MAIL_XX];
-  energy_sweeps_clamp(rsq, lane);
-  RN_WSYNC();
-  const float *yyl = rsq + 479;  // yy_lookup[i], i = 0..384
   best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch selection
   int offset = 0;
@@ -698,7 +727,37 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const float prev_gain = g.last_gain[s];
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
-    RN_WSYNC();  // the fine xcorr is dead from here on; its area becomes the dots
+    RN_WSYNC();  // the fine xcorr and the fine Syy are dead from here on
+    // yy_lookup = max(0, swept values) (src/pitch.c:452-455) moves out of the squares array into the dead areas, and the
+    // squares array becomes xs[i] = x_lp[i + 1]: every dot product below can then fetch its y operand 8 bytes at a time
+    // from an 8-byte aligned address, whatever the parity of its offset
+    float *yyl = scr + SCR_YYL, *xs = scr + SCR_XS;
+    {
+      float t[7], u[14];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {  // 385 = 6.02 x 64
+        const int i0 = lane + WAVE * k, i = i0 <= 384 ? i0 : 384;
+        const float v = rsq[479 + i];
+        t[k] = i ? fmaxf(0.f, v) : v;  // yy_lookup[0] = xx is stored as it is (src/pitch.c:450), MAX32(0, yy) for the others
+      }
+#pragma unroll
+      for (int k = 0; k < 14; k++) {
+        const int i0 = lane + WAVE * k + 1;
+        u[k] = xlp[i0 < 864 ? i0 : 863];
+      }
+      RN_WSYNC();
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const int i0 = lane + WAVE * k;
+        yyl[i0 <= 384 ? i0 : 384] = t[k];  // lanes past the end rewrite element 384 with its own value
+      }
+#pragma unroll
+      for (int k = 0; k < 14; k++) {
+        const int i0 = lane + WAVE * k;
+        if (i0 < 863) xs[i0] = u[k];
+      }
+    }
+    RN_WSYNC();
     // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
     // independent serial sum, so computing it speculatively changes no bit):
     //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
@@ -720,7 +779,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         off = Tc + (((lane - 32) & 1) ? 1 : -1);
         if (off < 0) off = 0;  // only for candidates the decision loop never selects (T1 < minperiod)
       }
-      if (off >= 0) dots[lane] = chain_dot8(x, x - off, N);
+      if (off >= 0) {
+        const int a = maxperiod - off;  // y = x_lp + a
+        dots[lane] = chain_dot8_y2(x, (a & 1) ? xs + (a - 1) : xlp + a, N);
+      }
     }
     RN_WSYNC();
     float xy = dots[1];
@@ -1157,10 +1219,10 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
   const int n = g->n_streams;
   const bool single = spw_force == 1 || (spw_force == 0 && n < RN_K1_MULTI_MIN_STREAMS);
   if (single) {
-    RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1 + K1_MAIL * 4, st, e0, e1, *g, *tb, slot, parity);
+    RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1, st, e0, e1, *g, *tb, slot, parity);
   } else {
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1 + K1_SPW * K1_MAIL * 4, st, e0, e1, *g, *tb, slot, parity);
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot, parity);
   }
   return hipGetLastError();
 }
@@ -1168,7 +1230,7 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
                                                int parity, const RnTrainArgs *tr, hipStream_t st) {
   hipError_t e = rn_launch_hp_passthrough(g, noisy, slot, st);  // training frames arrive filtered: K0 without the biquad
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds) + K1_MAIL * 4, st, *g, *tb,
+  hipLaunchKernelGGL(rn_train_features_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb,
                      slot, parity, *tr);
   return hipGetLastError();
 }

@@ -457,6 +457,7 @@ struct RNNModel {
 struct RNNoiseBatch {
   RNNModel *model = nullptr;
   int device = 0, n = 0, nn_path = 0;
+  int schedule = 0;  // 0: default (3-stream frame pipeline in multi-frame calls); 9: one stream; 1: only the high-pass aside
   int parity = 0;  // spectra slot (mod RN_SPEC_SLOTS) the next frame writes; the previous one holds the delayed spectra
   long frame_no = 0;  // selects the per-step scratch copy (features / silence / pitch are double-buffered)
   float *features2[2] = {nullptr, nullptr};
@@ -871,6 +872,13 @@ extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   return 0;
 }
 
+extern "C" int rnnoise_batch_set_schedule(RNNoiseBatch *b, int schedule) {
+  if (!b || (schedule != 0 && schedule != 1 && schedule != 9)) return -1;
+  const int old = b->schedule;
+  b->schedule = schedule;
+  return old;
+}
+
 extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
   if (!b || path < 0 || path > 1) return -1;
   if (path == 1 && !rn_nn_mfma_available()) return -1;
@@ -896,7 +904,8 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   // RNNOISE_AMD_PIPE (A/B runs only): 9 = no side streams, 1 = K0 on a side stream, 2 = K0 and K1 on side streams.
   // Measured after the fence-free events: the 3-stream schedule is the best or within noise of the best from 1 K to
   // 64 K streams (65,536: 20.2 M frames/s vs 20.0 M on one stream, 19.6 M with only K0 aside), so it is the only default.
-  static const int pipe_force = [] { const char *e = getenv("RNNOISE_AMD_PIPE"); return e ? atoi(e) : 0; }();
+  static const int pipe_env = [] { const char *e = getenv("RNNOISE_AMD_PIPE"); return e ? atoi(e) : 0; }();
+  const int pipe_force = b->schedule ? b->schedule : pipe_env;
   const bool pipelined = n_frames > 1 && pipe_force != 9;
   const bool side_k1 = pipelined && pipe_force != 1;
   if (pipelined && !b->side) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun): produces every artefact kept under profiles/ into gpurun_out/prof/.
-#   tools/collect_profiles.sh            -> bench lines, rocprofv3 kernel stats, PMC passes (4096 and 65536 streams)
+#   tools/collect_profiles.sh   -> bench lines (configs[1..3] + host-fed), rocprofv3 kernel stats, PMC passes, section taps
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof
@@ -8,17 +8,23 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
 last() { grep '^{' "$1" | tail -1; }
-python "$R/bench.py" > "$O/bench_4096.log" 2>&1;                                   last "$O/bench_4096.log" > "$O/bench_4096.json"
-python "$R/bench.py" --no-cpu-baseline --streams 65536 --steps 30 --warmup 6 > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_65536.json"
-python "$R/bench.py" --no-cpu-baseline --streams 32768 --steps 30 --warmup 6 > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_32768.json"
-python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_16384.json"
-python "$R/bench.py" --no-cpu-baseline --nn vector > "$O/b.log" 2>&1;             last "$O/b.log" > "$O/bench_4096_vector.json"
+python "$R/bench.py" > "$O/bench_65536.log" 2>&1;                                                        last "$O/bench_65536.log" > "$O/bench_65536.json"
+python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 > "$O/b.log" 2>&1;          last "$O/b.log" > "$O/bench_4096.json"
+python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 --nn vector > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_4096_vector.json"
+python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 > "$O/b.log" 2>&1;                 last "$O/b.log" > "$O/bench_little_32768.json"
+python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 > "$O/b.log" 2>&1;          last "$O/b.log" > "$O/bench_16384.json"
+python "$R/bench.py" --no-cpu-baseline --host-io --steps 8 --warmup 2 --repeats 9 > "$O/b.log" 2>&1;     last "$O/b.log" > "$O/bench_hostio_65536.json"
 python "$R/tools/serial_times.py" 4096 16384 65536 2>&1 | grep "N=" > "$O/serial_times.txt"
-rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline > "$O/trace.log" 2>&1
+python "$R/tools/k1_cycles.py" 65536 --nn 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
+python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"
+python "$R/tools/fft_bench.py" 2>&1 | grep -v amdgpu.ids > "$O/fft_bench.txt"
+rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline --repeats 5 > "$O/trace.log" 2>&1
 python "$R/tools/prof_summary.py" "$(ls "$O"/trace/*/*_results.db | head -1)" \
-  "python bench.py --no-cpu-baseline  [configs[1] workload: 4096 streams, MFMA network path, 3-stream pipeline]" > "$O/kernel_stats.txt"
-G="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES,SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR,TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum,FETCH_SIZE,WRITE_SIZE"
-python "$R/tools/pmc_collect.py" "$O/pmc_4096" "$G" -- python "$R/bench.py" --no-cpu-baseline --steps 6 --warmup 2 > "$O/pmc_4096.csv" 2>&1
-python "$R/tools/pmc_collect.py" "$O/pmc_65536" "$G" -- python "$R/bench.py" --no-cpu-baseline --streams 65536 --steps 6 --warmup 2 > "$O/pmc_65536.csv" 2>&1
-rm -rf "$O"/pmc_4096 "$O"/pmc_65536 "$O"/trace "$O"/b.log
+  "python bench.py --no-cpu-baseline --repeats 5  [configs[2]: 65536 streams, MFMA network path, 3-stream pipeline + one stand-alone pass]" > "$O/kernel_stats.txt"
+G="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES,SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT,TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum,FETCH_SIZE,WRITE_SIZE"
+# PMC passes on the one-stream schedule (RNNOISE_AMD_PIPE=9): a kernel's counters are then its own, not a neighbour's
+RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_65536" "$G" -- python "$R/bench.py" --no-cpu-baseline --steps 4 --warmup 1 --repeats 2 > "$O/pmc_65536.csv" 2>&1
+RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_4096" "$G" -- python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 8 --warmup 2 --repeats 2 > "$O/pmc_4096.csv" 2>&1
+RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_little_32768" "$G" -- python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 --steps 4 --warmup 1 --repeats 2 > "$O/pmc_little_32768.csv" 2>&1
+rm -rf "$O"/pmc_65536 "$O"/pmc_4096 "$O"/pmc_little_32768 "$O"/trace "$O"/b.log
 ls -la "$O"

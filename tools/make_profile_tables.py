@@ -11,11 +11,14 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-pre = sys.argv[3] if len(sys.argv) > 3 else "r1_final"
+pre = sys.argv[3] if len(sys.argv) > 3 else "r2"
 
-for n in ("bench_4096", "bench_16384", "bench_32768", "bench_65536", "bench_4096_vector"):
-    shutil.copy(os.path.join(src, n + ".json"), os.path.join(dst, f"{pre}_{n}.json"))
-shutil.copy(os.path.join(src, "serial_times.txt"), os.path.join(dst, f"{pre}_serial_times.txt"))
+for n in ("bench_65536", "bench_4096", "bench_4096_vector", "bench_16384", "bench_little_32768", "bench_hostio_65536"):
+    if os.path.exists(os.path.join(src, n + ".json")) and os.path.getsize(os.path.join(src, n + ".json")) > 10:
+        shutil.copy(os.path.join(src, n + ".json"), os.path.join(dst, f"{pre}_{n}.json"))
+for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench"):
+    if os.path.exists(os.path.join(src, n + ".txt")):
+        shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
 # kernel stats: our kernels, everything else (bench.py's torch input synthesis) folded into one line
 lines = open(os.path.join(src, "kernel_stats.txt")).read().split("\n")
@@ -31,33 +34,40 @@ for l in lines:
 out.append(f"(torch kernels of bench.py's input synthesis, outside the timed region)  calls {other_calls}  total_us {other_us:.1f}")
 open(os.path.join(dst, f"{pre}_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
 
-traffic = {}
-for n_streams in (4096, 65536):
-    rows = list(csv.DictReader(l for l in open(os.path.join(src, f"pmc_{n_streams}.csv")) if not l.startswith("#")))
-    hdr = (f"# PMC counters, mean per kernel launch: rocprofv3 --kernel-trace --pmc <group> -- python bench.py --no-cpu-baseline "
-           f"--streams {n_streams} --steps 6 --warmup 2  (MFMA path, pipelined)\n"
-           "# one run per counter group (tools/pmc_collect.py); SQ_* are summed over all shader engines\n"
-           "# HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is in KiB and on gfx950 reports 1/2 of wide coalesced reads "
-           "(MI355X_MICROARCH.md, HBM section)\n")
-    t = (f"{'kernel':<22}{'VALU/wave':>10}{'SALU/wave':>10}{'LDS/wave':>9}{'MFMA/wave':>10}{'VMEMrd/wave':>12}{'valu_busy%':>11}"
-         f"{'wait%':>7}{'L1acc/launch':>14}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}\n")
+by = {"default": {}, "little": {}}
+for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warmup 1 --repeats 2"),
+                                   ("4096", "default", 4096, "--streams 4096 --steps 8 --warmup 2 --repeats 2"),
+                                   ("little_32768", "little", 32768, "--model little --streams 32768 --steps 4 --warmup 1 --repeats 2")):
+    f = os.path.join(src, f"pmc_{tag}.csv")
+    if not os.path.exists(f):
+        continue
+    rows = list(csv.DictReader(l for l in open(f) if not l.startswith("#")))
+    hdr = (f"# PMC counters, mean per kernel launch: RNNOISE_AMD_PIPE=9 rocprofv3 --kernel-trace --pmc <group> -- python bench.py --no-cpu-baseline {cmd}\n"
+           "# (MFMA path, every kernel on one stream so that a kernel's counters are its own); one run per counter group (tools/pmc_collect.py);\n"
+           "# SQ_* are summed over all shader engines, *_CYCLES in quad-cycles; cyc/VALU = 4*SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU;\n"
+           "# LDS%/CU = SQ_LDS_IDX_ACTIVE / 256 CUs / (kernel duration x 2.1 GHz); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is in KiB\n"
+           "# and on gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section)\n")
+    t = (f"{'kernel':<26}{'waves':>8}{'VALU/wave':>10}{'SALU/wave':>10}{'LDS/wave':>9}{'MFMA/wave':>10}{'VMEM/wave':>10}{'cyc/VALU':>9}"
+         f"{'valu_act%':>10}{'wait%':>7}{'LDScyc/wave':>12}{'conflict%':>10}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}\n")
     for r in rows:
         def g(k):
             return float(r[k]) if r.get(k) else 0.0
         w = g("SQ_WAVES") or 1
         hbm = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / n_streams
-        t += (f"{r['kernel']:<22}{g('SQ_INSTS_VALU') / w:>10.0f}{g('SQ_INSTS_SALU') / w:>10.0f}{g('SQ_INSTS_LDS') / w:>9.0f}"
-              f"{g('SQ_INSTS_MFMA') / w:>10.0f}{g('SQ_INSTS_VMEM_RD') / w:>12.0f}"
-              f"{100 * g('SQ_ACTIVE_INST_VALU') / (g('SQ_WAVE_CYCLES') or 1):>11.1f}{100 * g('SQ_WAIT_ANY') / (g('SQ_WAVE_CYCLES') or 1):>7.1f}"
-              f"{g('TCP_TOTAL_CACHE_ACCESSES_sum'):>14.0f}{100 * g('TCC_HIT_sum') / ((g('TCC_HIT_sum') + g('TCC_MISS_sum')) or 1):>8.1f}"
+        cpi = 4 * g("SQ_ACTIVE_INST_VALU") / (g("SQ_INSTS_VALU") or 1)
+        t += (f"{r['kernel']:<26}{w:>8.0f}{g('SQ_INSTS_VALU') / w:>10.0f}{g('SQ_INSTS_SALU') / w:>10.0f}{g('SQ_INSTS_LDS') / w:>9.0f}"
+              f"{g('SQ_INSTS_MFMA') / w:>10.0f}{(g('SQ_INSTS_VMEM_RD') + g('SQ_INSTS_VMEM_WR')) / w:>10.0f}{cpi:>9.2f}"
+              f"{100 * g('SQ_ACTIVE_INST_VALU') / (g('SQ_WAVE_CYCLES') or 1):>10.1f}{100 * g('SQ_WAIT_ANY') / (g('SQ_WAVE_CYCLES') or 1):>7.1f}"
+              f"{g('SQ_LDS_IDX_ACTIVE') / w:>12.0f}{100 * g('SQ_LDS_BANK_CONFLICT') / (g('SQ_LDS_IDX_ACTIVE') or 1):>10.1f}"
+              f"{100 * g('TCC_HIT_sum') / ((g('TCC_HIT_sum') + g('TCC_MISS_sum')) or 1):>8.1f}"
               f"{g('FETCH_SIZE'):>11.0f}{g('WRITE_SIZE'):>11.0f}{hbm:>12.0f}\n")
-        traffic.setdefault(str(n_streams), {})[r["kernel"].replace("_lean", "")] = {
-            "hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"),
-            "write_kib_per_launch": g("WRITE_SIZE"), "kernel": r["kernel"]}
-    open(os.path.join(dst, f"{pre}_pmc_{n_streams}.txt"), "w").write(hdr + t)
-json.dump({"source": f"profiles/{pre}_pmc_4096.txt, {pre}_pmc_65536.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                     "gfx950 x2 read correction); bench.py uses the set measured nearest to its batch size",
-           "by_streams": traffic},
-          open(os.path.join(dst, "r1_traffic.json"), "w"), indent=1)
-print(open(os.path.join(dst, f"{pre}_pmc_4096.txt")).read())
-print(open(os.path.join(dst, f"{pre}_pmc_65536.txt")).read())
+        by[model].setdefault(str(n_streams), {})[r["kernel"].replace("_single", "")] = {
+            "hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"), "write_kib_per_launch": g("WRITE_SIZE"),
+            "valu_per_wave": round(g("SQ_INSTS_VALU") / w), "valu_cycles_per_inst": round(cpi, 2),
+            "lds_cycles_per_wave": round(g("SQ_LDS_IDX_ACTIVE") / w), "kernel": r["kernel"], "source": f"profiles/{pre}_pmc_{tag}.txt"}
+    open(os.path.join(dst, f"{pre}_pmc_{tag}.txt"), "w").write(hdr + t)
+    print(hdr + t)
+json.dump({"source": f"profiles/{pre}_pmc_*.txt (rocprofv3 --pmc, separate passes, gfx950 x2 read correction); bench.py uses the set of its "
+                     "model measured nearest to its batch size",
+           "by_streams": by["default"], "little": by["little"]},
+          open(os.path.join(dst, "pmc_by_streams.json"), "w"), indent=1)
