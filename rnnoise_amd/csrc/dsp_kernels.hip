@@ -168,8 +168,8 @@ __device__ __forceinline__ void band_products(float *Q, const float (&xr)[NX], c
     float tmp = xr[j] * yr[j];
     tmp += xi[j] * yi[j];
     if (bin < 400) {
-      Q[(q >> 10) & 0x3ff] = frac * tmp;
-      Q[q & 0x3ff] = (1 - frac) * tmp;
+      Q[(q >> 11) & 0x7ff] = frac * tmp;
+      Q[q & 0x7ff] = (1 - frac) * tmp;
     }
   }
 }
@@ -463,7 +463,10 @@ __device__ __forceinline__ v2f chain_dot8_x2(const float *x, const v2f *z, int n
 }
 
 struct AnalysisLds {
-  float a[2368];  // 9,472 B: three of these workgroups (4 arenas each) leave 50 KB of a CU's LDS to a network-kernel tile
+  // 9,504 B: three of these workgroups (4 arenas each) leave 49 KB of a CU's LDS to a network-kernel tile.  2376 = 8 (mod 32):
+  // the arenas of a workgroup start 8 banks apart, so when wave 0 walks the same index of all four streams in a narrow phase
+  // the four accesses fall on different banks (with a multiple of 32 they were 4-way conflicts)
+  float a[2376];
 };
 #define SCR_XLP 0
 #define SCR_SQ 864    // [864]  fine search: reversed squares of xlp, later yy_lookup
@@ -476,9 +479,9 @@ struct AnalysisLds {
 #define SCR_DOTS 2120 // [64]  doubling dots (behind yy_lookup, over the dead fine xcorr)
 #define SCR_YYL 1732  // [385] yy_lookup after the fine search (over the dead Syy / fine xcorr areas)
 #define SCR_XS 864    // [864] x_lp shifted by one sample, for the 8-byte reads of the doubling dots (over the dead squares)
-#define SCR_Q 1084    // [864]  band products (above the padded bins 0..480 = floats [0,1082))
+#define SCR_Q 960     // [1052] band products in the layout of RnTablesDev::band_q (behind the staged window)
 #define SCR_EX 2336   // [32]  band energies of X: the one vector that lives from the first transform to the features
-#define SCR_MISC 1952 // sums[40] | Ep[32] | Exp[32] | Ly[32]: transform phases only (behind the band products)
+#define SCR_MISC 2012 // sums[40] | Ep[32] | Exp[32] | Ly[32]: transform phases only (behind the band products)
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
@@ -1040,7 +1043,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   // ---- every HBM operand up front ----
   float2 X[NBIN], P[NBIN];
   float frac[NBIN];
-  uint32_t bq[NBIN];  // RnTablesDev::band_q: slot of the (1-frac) term | slot of the frac term << 10 | band << 20
+  uint32_t bq[NBIN];  // RnTablesDev::band_q: slot of the (1-frac) term | slot of the frac term << 11 | band << 22
 #pragma unroll
   for (int j = 0; j < NBIN; j++) {
     const int bin = pos + WAVE * j;
@@ -1071,7 +1074,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   }
 
 // src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
-#define BAND(j) ((int)(bq[j] >> 20))
+#define BAND(j) ((int)(bq[j] >> 22))
 #define INTERP(vec, j)                                                                                      \
   ((pos + WAVE * (j)) >= 400 ? 0.f                                                                          \
    : BAND(j) == 0 ? (vec)[0]                                                                                \
@@ -1099,8 +1102,8 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       if (bin < 400) {
         float tmp = X[j].x * X[j].x;
         tmp += X[j].y * X[j].y;
-        Q[(bq[j] >> 10) & 0x3ff] = frac[j] * tmp;
-        Q[bq[j] & 0x3ff] = (1 - frac[j]) * tmp;
+        Q[(bq[j] >> 11) & 0x7ff] = frac[j] * tmp;
+        Q[bq[j] & 0x7ff] = (1 - frac[j]) * tmp;
       }
     }
     band_chain(newE, Q, sums, tb, lane);

@@ -36,7 +36,7 @@ struct RnTablesDev {
   const uint8_t *band_of_bin; // [400]   band index i with eband[i] <= bin < eband[i+1]
   const uint32_t *rcp_lut;    // [2048]  x86 rcpps stand-in (oracle/rcp_capture.c)
   const float *fft_tw;        // [16][64][2] per-lane twiddles of the register-resident FFT (fft_reg.h: RN_FTW_*)
-  const uint32_t *band_q;     // [400]  per bin: LDS slot of its (1-frac) term | slot of its frac term << 10 | band << 20
+  const uint32_t *band_q;     // [400]  per bin: LDS slot of its (1-frac) term | slot of its frac term << 11 | band << 22
   const uint32_t *band_chain; // [34]   per band accumulator: first slot (16-byte aligned) | number of terms << 16
   double dct_scale;           // sqrt(2./22), src/denoise.c:168
 };
