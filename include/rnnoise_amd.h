@@ -29,9 +29,8 @@ RNNOISE_EXPORT int rnnoise_amd_device_count(void);
 
 /* Create N zero-initialised streams on `device`, all using `model` (must outlive the
  * batch, like rnnoise_create()).  NULL on error (no GPU, bad model, out of memory).
- * model==NULL fails: this build carries no compiled-in weights (the reference fetches
- * them with download_model.sh; it is equivalent to a -DUSE_WEIGHTS_FILE build,
- * src/denoise.c:298-303). */
+ * model==NULL fails here (the drop-in entry points rnnoise_create / rnnoise_init fall back
+ * to $RNNOISE_AMD_DEFAULT_MODEL; the batched API wants the model spelled out). */
 RNNOISE_EXPORT RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, int device);
 RNNOISE_EXPORT void rnnoise_batch_destroy(RNNoiseBatch *b);
 RNNOISE_EXPORT int rnnoise_batch_size(const RNNoiseBatch *b);
@@ -39,12 +38,16 @@ RNNOISE_EXPORT int rnnoise_batch_size(const RNNoiseBatch *b);
 /* Back to the state rnnoise_init() produces (all zeros). 0 / -1. */
 RNNOISE_EXPORT int rnnoise_batch_reset(RNNoiseBatch *b);
 
-/* Host buffers; synchronous.  vad and gains may be NULL.  in may alias out. 0 / -1. */
+/* Host buffers; synchronous.  vad and gains may be NULL.  in may alias out. 0 / -1.
+ * Internally a double-buffered pipeline: ~32 MB chunks, upload of chunk i+1 and download of chunk i-1 overlap the
+ * kernels of chunk i.  Pinned host memory (hipHostMalloc / hipHostRegister) is used in place by DMA; pageable memory
+ * goes through the library's pinned bounce buffers. */
 RNNOISE_EXPORT int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
                                          int n_frames);
 
-/* Device-resident buffers (same shapes, memory of the batch's device); asynchronous on
- * `hip_stream` (a hipStream_t, NULL = default stream).  This is the throughput path. */
+/* Device-resident buffers (same shapes, memory of the batch's device, 16-byte aligned: the
+ * kernels read and write them 16 bytes per lane); asynchronous on `hip_stream` (a hipStream_t,
+ * NULL = default stream).  This is the throughput path. */
 RNNOISE_EXPORT int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
                                                 float *d_gains, int n_frames, void *hip_stream);
 
