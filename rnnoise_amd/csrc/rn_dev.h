@@ -90,6 +90,8 @@ struct RnGroupDev {
   float *vad;          // [N]
   float *lpc2;         // [RN_RING_SLOTS][N][8] (5 used) FIR taps of rnn_pitch_downsample, produced by K0, consumed by K1
   float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)
+  int8_t *act_q[2];    // [ceil(N/16)][6144] layer-wise network: quantised layer input per 16-stream tile, B-fragment order
+                       //   (ping-pong: layer k reads [k & 1], writes [(k + 1) & 1]); whole batches only, never offset by views
   float *train_clean_mem;  // [N][480] analysis memory of the clean stream (training-feature extraction only)
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };

@@ -32,6 +32,8 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *
                                           hipEvent_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                         hipEvent_t);
+extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
+                                          hipEvent_t);
 extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
@@ -692,6 +694,16 @@ T *carve(uint8_t *&p, size_t count) {
   return r;
 }
 
+// Batches from this size up run the network layer by layer (nn_layers.hip: 64 streams per GRU workgroup); below it the
+// five launches and the smaller grids cost more than the weight reuse gains.  $RNNOISE_AMD_NN_LAYERS_MIN overrides (A/B runs).
+int nn_layers_min_streams() {
+  static const int v = [] {
+    const char *e = getenv("RNNOISE_AMD_NN_LAYERS_MIN");
+    return e ? atoi(e) : 16384;
+  }();
+  return v;
+}
+
 size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   uint8_t *p = base;
   size_t N = n;
@@ -720,6 +732,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
   g.nn_act = carve<float>(p, RN_GRU * N);
+  for (int k = 0; k < 2; k++) g.act_q[k] = carve<int8_t>(p, (N + 15) / 16 * 6144);
   g.lpc2 = carve<float>(p, 8 * N * RN_RING_SLOTS);
   g.train_clean_mem = carve<float>(p, RN_FRAME_SIZE * N);
   return (size_t)(p - base);
@@ -896,8 +909,8 @@ extern "C" int rnnoise_batch_set_schedule(RNNoiseBatch *b, int schedule) {
 }
 
 extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
-  if (!b || path < 0 || path > 1) return -1;
-  if (path == 1 && !rn_nn_mfma_available()) return -1;
+  if (!b || path < 0 || path > 2) return -1;  // 0 vector, 1 MFMA (layer-wise from nn_layers_min_streams() up), 2 layer-wise
+  if (path >= 1 && !rn_nn_mfma_available()) return -1;
   int old = b->nn_path;
   b->nn_path = path;
   return old;
@@ -994,7 +1007,10 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     }
     {
       TimedLaunch t(b, 1);
-      if (b->nn_path == 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+      const bool whole = g.n_streams == g.n_stride;  // (the layer images are indexed by tile of the whole batch)
+      if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams())))
+        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+      else if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
       else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
     }
     {

@@ -353,10 +353,11 @@ def test_device_resident_path_with_torch_stream(model, blob_default):
 
 
 # ---- batched MFMA network path (rnnoise_batch_set_nn_path(b, 1)) -------------------------------
-@pytest.mark.parametrize("n,path", [(4, 1), (17, 1), (64, 1), (65, 1), (17, 0), (65, 0)])
+@pytest.mark.parametrize("n,path", [(4, 1), (17, 1), (64, 1), (65, 1), (17, 0), (65, 0), (5, 2), (17, 2), (64, 2), (65, 2), (130, 2)])
 def test_mfma_path_bit_exact(model, blob_default, n, path):
     """int8 MFMA on zero-filled dense tiles + f32 MFMA chains = same bits as the oracle, for tile
-    counts that do and do not divide 16, with silent and non-silent streams mixed in one tile"""
+    counts that do and do not divide 16, with silent and non-silent streams mixed in one tile.
+    path 2 = the layer-wise schedule large batches take (64 streams per GRU workgroup: ragged tiles AND ragged groups)"""
     T = 40
     ids = [(3 * s) % 11 for s in range(n)]
     pcm = synth.batch_pcm(ids, T, lead_silence=0)
@@ -418,12 +419,15 @@ def test_pipeline_chunking_is_invisible(model, blob_default):
     pcm = synth.batch_pcm(streams, T, lead_silence=1)
     pcm[17:20, 1] = 0  # a silent gap in one stream (network state must freeze across a call boundary too)
     want = oracle_run(blob_default, pcm)
-    for path in (1, 0):
+    for path in (2, 1, 0, -1):     # -1: a different network schedule at every call (they share all state)
         b = capi.Batch(model, len(streams))
-        b.set_nn_path(path)
+        if path >= 0:
+            b.set_nn_path(path)
         outs, vads, gains = [], [], []
         t = 0
         for n in [1, 2, 5, 1, 3, 7, 1, 1, 4, 6, 2, 12]:
+            if path < 0:
+                b.set_nn_path((2, 0, 1)[len(outs) % 3])
             o, v, g = b.process(pcm[t:t + n])
             outs.append(o); vads.append(v); gains.append(g)
             t += n

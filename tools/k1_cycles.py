@@ -12,7 +12,7 @@ m = capi.Model(blob)
 for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
     b = capi.Batch(m, n)
     b.debug_pitch(arm_only=True)
-    b.set_nn_path(1)
+    b.set_nn_path(2 if "--layers" in sys.argv and n >= 64 else 1)
     pcm = np.ascontiguousarray(np.tile(synth.batch_pcm(range(min(n, 16)), 6), (1, (n + 15) // 16, 1))[:, :n])
     b.process(pcm)
     d = b.debug_pitch()
@@ -21,6 +21,11 @@ for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
         print(f"--- N={n}: MFMA network kernel, mean shader clocks per phase over tiles (total {clk2.sum(1).mean():.0f}) ---")
         for k, name in enumerate(["load+quantise", "conv1", "conv2", "gru1", "gru2", "gru3", "dense/vad"]):
             print(f"  {name:<20} {clk2[:, k].mean():>10.0f}  {100 * clk2[:, k].mean() / clk2.sum(1).mean():5.1f}%")
+        if n >= 64 and "--layers" in sys.argv:
+            c = d[::64, 1367:1376]
+            print("    layer-wise GRU kernel (wave 0 of each 64-stream workgroup): prologue issue | wait to barrier | 3 unit tiles")
+            for k in range(3):
+                print(f"    gru{k+1}: {c[:, 3*k].mean():9.0f} {c[:, 3*k+1].mean():9.0f} {c[:, 3*k+2].mean():9.0f}")
     clk = d[:, 1348:1360]
     print(f"--- N={n}: mean shader clocks per section over streams (total {clk.sum(1).mean():.0f}) ---")
     for k, name in enumerate(NAMES):
