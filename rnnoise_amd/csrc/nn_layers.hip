@@ -15,10 +15,13 @@
 #define GTHREADS (64 * GW)
 
 struct GruLds {
-  uint32_t lut[2048];            // rcpps table
+  uint32_t lut[2048];            // rcpps table, pre-biased (rcp_b below)
   int8_t xq[GM][KT * 64 * 16];   // layer input images
-  int8_t hq[GM][KT * 64 * 16];   // quantised recurrent state
+  int8_t hq[GM][KT * 64 * 16];   // recurrent state images
+  float hrow[GW][24 / GW][GM * TS][16];  // per wave and unit tile: the f32 state of its 16 units for the workgroup's 64 streams
+                                         // (the blend z*h + (1-z)*candidate needs them exact)
 };
+static_assert(sizeof(GruLds) <= 160 * 1024, "one workgroup per CU, all of its LDS");
 
 // acc[gate][t] += W(row tile 24 gate + u) . image[t]: the three gates of a unit tile share the layer input, so one B
 // fragment read from LDS feeds three MFMAs and one A fragment from L2 four.  (Measured with the 1 x 4 blocking of the
@@ -27,15 +30,78 @@ struct GruLds {
 // Addressing is (uniform base, unsigned 32-bit offset) throughout this file: the SGPR-base + VGPR-offset form of global_load.
 // The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
 // boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
+// (uniform base, unsigned 32-bit BYTE offset): the form the compiler turns into global_load ..., v_off, s[base:base+1]
+template <typename T>
+__device__ __forceinline__ T ldg(const void *base, unsigned byte_off) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void stg(void *base, unsigned byte_off, T v) {
+  *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+// ---- the activations and the quantiser of nn_common.h with fewer VALU operations (this kernel's main loop is VALU-bound) ----
+// Same bits for every finite argument -- which is all a GRU layer can see: its pre-activations are int32 sums times
+// finite scales plus diag * h, and h stays in [-1, 1] from a zero or any finite start.  What differs from nn_common.h:
+//   * the reciprocal's table arrives pre-biased (lut_b[i] = lut[i] + 0x3f800000), (a - (e - bias)) == ((a + bias) - e) mod 2^32;
+//   * the two clamps are one v_med3_f32 (differs from the x86 min/max pair only for a NaN argument);
+//   * the u8 quantiser is v_rndne + v_cvt_pk_u8_f32 (saturating both ways like packs/packus; differs only for
+//     |127 x + 127| >= 2^31, where cvtps2dq's "integer indefinite" turns a huge positive value into 0).
+__device__ __forceinline__ float rcp_b(float x, const uint32_t *lut_b) {
+  const uint32_t b = __float_as_uint(x);
+  return __uint_as_float(lut_b[(b >> 12) & 0x7ff] - (b & 0x7f800000u));
+}
+__device__ __forceinline__ float tanh_g(float x, const uint32_t *lut_b) {  // src/vec_avx.h:398-416
+  const float N0 = 952.52801514f, N1 = 96.39235687f, N2 = 0.60863042f;
+  const float D0 = 952.72399902f, D1 = 413.36801147f, D2 = 11.88600922f;
+  const float x2 = x * x;
+  float num = fmaf(fmaf(N2, x2, N1), x2, N0);
+  const float den = fmaf(fmaf(D2, x2, D1), x2, D0);
+  num = num * x;
+  num = num * rcp_b(den, lut_b);
+  return __builtin_amdgcn_fmed3f(num, -1.f, 1.f);
+}
+__device__ __forceinline__ float sigmoid_g(float x, const uint32_t *lut_b) {  // src/vec_avx.h:426-445
+  const float N0 = 238.13200378f, N1 = 6.02452230f, N2 = 0.00950985f;
+  const float D0 = 952.72399902f, D1 = 103.34200287f, D2 = 0.74287558f;
+  const float x2 = x * x;
+  float num = fmaf(fmaf(N2, x2, N1), x2, N0);
+  const float den = fmaf(fmaf(D2, x2, D1), x2, D0);
+  num = num * x;
+  num = fmaf(num, rcp_b(den, lut_b), .5f);
+  return __builtin_amdgcn_fmed3f(num, 0.f, 1.f);
+}
+__device__ __forceinline__ int pack4_g(float a, float b, float c, float d) {  // src/vec_avx.h:326-341, then -128 per byte
+  unsigned p = 0;
+  p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a, 127.f, 127.f)), 0, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(b, 127.f, 127.f)), 1, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(c, 127.f, 127.f)), 2, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(d, 127.f, 127.f)), 3, p);
+  return (int)(p ^ 0x80808080u);
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at lds_dst (wave-uniform byte address).
+// Issued from asm so that hipcc does not count it: it would otherwise drain the piece (vmcnt) before the next LDS read of
+// ANY address.  The waits are explicit below; hipcc's own vmcnt(N) for its loads can only over-wait (in-order counter).
+__device__ __forceinline__ void dma_1k(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // (wave-uniform by construction, but derived from threadIdx: not provably)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
 #define AD 2
 struct AFrags {
   v4i f[AD + 1][3];
 };
 __device__ __forceinline__ void a_fetch(AFrags &A, int step, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr, unsigned a0) {
-  const v4i *a = reinterpret_cast<const v4i *>(step < KT ? wi : wr);
+  const int8_t *a = step < KT ? wi : wr;
   const int kt = step < KT ? step : step - KT;
 #pragma unroll
-  for (int gate = 0; gate < 3; gate++) A.f[step % (AD + 1)][gate] = a[a0 + (unsigned)((gate * 24 * KT + kt) * 64)];
+  for (int gate = 0; gate < 3; gate++) A.f[step % (AD + 1)][gate] = ldg<v4i>(a, a0 + (unsigned)((gate * 24 * KT + kt) * 1024));
 }
 // k-steps [s0, s0 + KT) of the rolling sequence: acc[gate][t] += A(step)[gate] . image[t]
 __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags &A, int s0, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr,
@@ -59,13 +125,14 @@ __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags &A, int s0, co
 }
 
 extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  __shared__ __attribute__((aligned(16))) GruLds L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
   const int N = g.n_streams, n_tiles = (N + TS - 1) / TS, tile0 = blockIdx.x * GM;
   const uint32_t *lut = L.lut;
   float *st = g.gru_state + (size_t)layer * g.n_stride * RN_GRU;
-  const int8_t *xin = g.act_q[layer & 1];
-  int8_t *xout = g.act_q[(layer + 1) & 1];
+  const int8_t *xin = g.act_q[layer];
+  int8_t *himg = g.act_q[layer + 1];  // quantised state: read here, rewritten below (own tiles only)
 
   // (tests / profiling: shader-clock taps of wave 0, slots RN_DBG_CLK2 + 7 + 3 * layer + {0: prologue, 1: loads issued -> barrier, 2: tiles})
   float *dbg = (g.debug && tid == 0) ? g.debug + (size_t)tile0 * TS * RN_DBG_FLOATS + RN_DBG_CLK2 + 7 + 3 * layer : nullptr;
@@ -78,103 +145,110 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
     sn[t] = s < N ? s : N - 1;
     sil[t] = g.silence[(unsigned)sn[t]];
   }
-  // all loads of the prologue in flight at once (constant trip counts, fully unrolled): one HBM round trip, not twelve
+  // Prologue: the two images of the workgroup's GM tiles and the rcpps table go straight from HBM to LDS (1 KB per wave
+  // instruction, no staging registers, no ds_write pass: the images are stored in exactly the order LDS wants), then
+  // this wave's f32 rows for its first unit tile.
+  auto rows_fetch = [&](int ui) {  // f32 state of units 16 u .. 16 u + 15, u = wave + GW ui, of the 64 streams: 4 pieces
+    const int u = wave + GW * ui;
+#pragma unroll
+    for (int i = 0; i < GM * TS * 16 * 4 / 1024; i++) {
+      const int idx = i * 64 + lane, row = idx >> 2, seg = idx & 3, s = tile0 * TS + row, sc = s < N ? s : N - 1;
+      dma_1k(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), lds_addr(&L.hrow[wave][ui][0][0]) + i * 1024);
+    }
+  };
   {
-    constexpr int NX = GM * KT * 64 / GTHREADS, NH = GM * TS * 96 / GTHREADS;  // 3 and 12 16-byte loads per thread
-    static_assert(NX * GTHREADS == GM * KT * 64 && NH * GTHREADS == GM * TS * 96, "prologue tiling");
-    v4i xi[NX];
-    v4f hs[NH];
+    constexpr int NCHUNK = 2 * GM * KT;  // 1 KB pieces
 #pragma unroll
-    for (int j = 0; j < NX; j++) {
-      const int i = tid + j * GTHREADS, t = i / (KT * 64), o = i - t * (KT * 64), tile = (tile0 + t < n_tiles) ? tile0 + t : n_tiles - 1;
-      xi[j] = reinterpret_cast<const v4i *>(xin)[(unsigned)(tile * (KT * 64) + o)];
+    for (int j = 0; j < (NCHUNK + GW - 1) / GW; j++) {
+      const int c = wave + j * GW;  // wave-uniform
+      if (c < NCHUNK) {
+        const int which = c / (GM * KT), cc = c - which * (GM * KT), t = cc / KT, kt = cc - t * KT;
+        const int tile = (tile0 + t < n_tiles) ? tile0 + t : n_tiles - 1;
+        dma_1k((which ? himg : xin) + ((size_t)tile * (KT * 64 * 16) + kt * 1024 + lane * 16), lds_addr(which ? L.hq[t] : L.xq[t]) + kt * 1024);
+      }
     }
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int e = tid + j * GTHREADS, q = e / 96, c = e - q * 96, s = (tile0 * TS + q < N) ? tile0 * TS + q : N - 1;
-      hs[j] = reinterpret_cast<const v4f *>(st)[(unsigned)(s * 96 + c)];
-    }
-#pragma unroll
-    for (int j = 0; j < (2048 + GTHREADS - 1) / GTHREADS; j++)
-      if (tid + j * GTHREADS < 2048) L.lut[tid + j * GTHREADS] = tb.rcp_lut[tid + j * GTHREADS];
-#pragma unroll
-    for (int j = 0; j < NX; j++) {
-      const int i = tid + j * GTHREADS, t = i / (KT * 64), o = i - t * (KT * 64);
-      reinterpret_cast<v4i *>(L.xq[t])[o] = xi[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NH; j++) {  // quantise the old state
-      const int e = tid + j * GTHREADS, q = e / 96, c4 = (e - q * 96) << 2;
-      *reinterpret_cast<int *>(L.hq[q >> 4] + frag_off(q & 15, c4)) = pack4(hs[j][0], hs[j][1], hs[j][2], hs[j][3]);
-    }
+    static_assert(GW >= 8, "the LUT is 8 pieces");
+    if (wave < 8) dma_1k(tb.rcp_lut_b + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
+    rows_fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   const unsigned long long clk1 = g.debug ? __builtin_amdgcn_s_memtime() : 0;
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
   const unsigned long long clk2 = g.debug ? __builtin_amdgcn_s_memtime() : 0;
 
 #pragma unroll
   for (int t = 0; t < GM; t++) live[t] = (tile0 + t) * TS + n < N && !sil[t];  // silent streams keep their state (src/denoise.c:474)
   const RnLinearDev &wi = m.gru_in[layer], &wr = m.gru_rec[layer];
 #pragma unroll 1
-  for (int u = wave; u < 24; u += GW) {
-    const int unit0 = 16 * u + 4 * gq;
+  for (int ui = 0; ui < 24 / GW; ui++) {
+    const int u = wave + GW * ui, unit0 = 16 * u + 4 * gq;
     v4i acc[3][GM];
     v4f gi[3][GM], h_old[GM];
+    // (the accumulators start from 128 * rowsum(w): acc_x86 = acc_mfma + 128 rowsum, nn_mfma.hip, without an add per value)
 #pragma unroll
-    for (int t = 0; t < GM; t++) h_old[t] = reinterpret_cast<const v4f *>(st)[(unsigned)(sn[t] * (RN_GRU / 4) + (unit0 >> 2))];
+    for (int gate = 0; gate < 3; gate++) {
+      const v4i rs = ldg<v4i>(wi.rowsum128, (unsigned)(gate * RN_GRU + unit0) * 4u);
 #pragma unroll
-    for (int gate = 0; gate < 3; gate++)
-#pragma unroll
-      for (int t = 0; t < GM; t++) acc[gate][t] = v4i{0, 0, 0, 0};
-    const unsigned a0 = (unsigned)(u * KT * 64 + lane);
+      for (int t = 0; t < GM; t++) acc[gate][t] = rs;
+    }
+    const unsigned a0 = (unsigned)(u * KT * 64 + lane) * 16u;  // byte offset of this lane's first A fragment
     AFrags A;
 #pragma unroll
     for (int step = 0; step < AD; step++) a_fetch(A, step, wi.wmf, wr.wmf, a0);
     int8_gates(acc, A, 0, wi.wmf, wr.wmf, a0, lane, L.xq);
 #pragma unroll
     for (int gate = 0; gate < 3; gate++) {  // float(acc_x86)*scale + subias (src/nnet_arch.h:145-151)
-      const unsigned row4 = (unsigned)(gate * RN_GRU + unit0) >> 2;
-      const v4i rs = reinterpret_cast<const v4i *>(wi.rowsum128)[row4];
-      const v4f sc = reinterpret_cast<const v4f *>(wi.scale)[row4];
-      const v4f sb = reinterpret_cast<const v4f *>(wi.bias)[row4];
+      const unsigned row4 = (unsigned)(gate * RN_GRU + unit0) * 4u;  // byte offset of the 4 rows
+      const v4f sc = ldg<v4f>(wi.scale, row4);
+      const v4f sb = ldg<v4f>(wi.bias, row4);
+      const v4i rs = ldg<v4i>(wr.rowsum128, row4);
 #pragma unroll
-      for (int t = 0; t < GM; t++)
+      for (int t = 0; t < GM; t++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          gi[gate][t][r] = (float)(acc[gate][t][r] + rs[r]) * sc[r] + sb[r];
-          acc[gate][t][r] = 0;
-        }
+        for (int r = 0; r < 4; r++) gi[gate][t][r] = (float)acc[gate][t][r] * sc[r] + sb[r];
+        acc[gate][t] = rs;
+      }
     }
     int8_gates(acc, A, KT, wi.wmf, wr.wmf, a0, lane, L.hq);
+    // all of this wave's loads have landed (the last A fragment was just used): its f32 rows for this tile are in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][ui][TS * t + n][4 * gq]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     v4f gr[3][GM];
 #pragma unroll
     for (int gate = 0; gate < 3; gate++) {
-      const unsigned row4 = (unsigned)(gate * RN_GRU + unit0) >> 2;
-      const v4i rs = reinterpret_cast<const v4i *>(wr.rowsum128)[row4];
-      const v4f sc = reinterpret_cast<const v4f *>(wr.scale)[row4];
-      const v4f sb = reinterpret_cast<const v4f *>(wr.bias)[row4];
-      const v4f dg = reinterpret_cast<const v4f *>(wr.diag)[row4];
+      const unsigned row4 = (unsigned)(gate * RN_GRU + unit0) * 4u;  // byte offset of the 4 rows
+      const v4f sc = ldg<v4f>(wr.scale, row4);
+      const v4f sb = ldg<v4f>(wr.bias, row4);
+      const v4f dg = ldg<v4f>(wr.diag, row4);
 #pragma unroll
       for (int t = 0; t < GM; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          gr[gate][t][r] = (float)(acc[gate][t][r] + rs[r]) * sc[r] + sb[r];
+          gr[gate][t][r] = (float)acc[gate][t][r] * sc[r] + sb[r];
           gr[gate][t][r] += dg[r] * h_old[t][r];  // src/nnet_arch.h:153-161
         }
     }
+    // The next tile's rows start their HBM trip here, under the ~4k cycles of activation VALU work that load nothing:
+    // vmcnt retires in order, so any load issued behind them (the constants above, the next A fragments) waits them out.
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + GW < 24) rows_fetch(ui + 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < GM; t++) {
       v4f hn;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float z = sigmoid_x86(gi[0][t][r] + gr[0][t][r], lut);
-        const float rg = sigmoid_x86(gi[1][t][r] + gr[1][t][r], lut);
-        const float hh = tanh_x86(gi[2][t][r] + gr[2][t][r] * rg, lut);
+        const float z = sigmoid_g(gi[0][t][r] + gr[0][t][r], lut);
+        const float rg = sigmoid_g(gi[1][t][r] + gr[1][t][r], lut);
+        const float hh = tanh_g(gi[2][t][r] + gr[2][t][r] * rg, lut);
         hn[r] = z * h_old[t][r] + (1 - z) * hh;
       }
-      if (live[t]) reinterpret_cast<v4f *>(st)[(unsigned)(sn[t] * (RN_GRU / 4) + (unit0 >> 2))] = hn;
-      if (layer < 2 && tile0 + t < n_tiles)
-        reinterpret_cast<int *>(xout)[(unsigned)((tile0 + t) * (KT * 64 * 16) + frag_off(n, unit0)) >> 2] = pack4(hn[0], hn[1], hn[2], hn[3]);
+      if (live[t]) {  // (live implies tile0 + t < n_tiles)
+        stg<v4f>(st, (unsigned)(sn[t] * RN_GRU + unit0) * 4u, hn);
+        stg<int>(himg, (unsigned)((tile0 + t) * (KT * 64 * 16) + frag_off(n, unit0)), pack4_g(hn[0], hn[1], hn[2], hn[3]));
+      }
     }
   }
   if (dbg && tile0 * TS < N) {
@@ -187,6 +261,26 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
 
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
-  hipLaunchKernelGGL(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), 0, st, *g, *m, *tb, layer);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_gru_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, *g, *m, *tb, layer);
+  return hipGetLastError();
+}
+
+// Rebuilds the state images act_q[1..3] from the f32 GRU state (after a reset, an import, or steps taken by the other
+// network kernels): one workgroup per (tile, layer).
+extern "C" __global__ void __launch_bounds__(256) rn_nn_requant_kernel(RnGroupDev g) {
+  const int tile = blockIdx.x, layer = blockIdx.y, N = g.n_streams;
+  const float *st = g.gru_state + (size_t)layer * g.n_stride * RN_GRU;
+  int8_t *img = g.act_q[layer + 1] + (size_t)tile * (KT * 64 * 16);
+  for (int e = threadIdx.x; e < TS * 96; e += 256) {
+    const int q = e / 96, c4 = (e - q * 96) << 2, s = (tile * TS + q < N) ? tile * TS + q : N - 1;
+    const v4f h = *reinterpret_cast<const v4f *>(st + (size_t)s * RN_GRU + c4);
+    *reinterpret_cast<int *>(img + frag_off(q, c4)) = pack4(h[0], h[1], h[2], h[3]);
+  }
+}
+extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *g, hipStream_t st) {
+  hipLaunchKernelGGL(rn_nn_requant_kernel, dim3((g->n_streams + TS - 1) / TS, 3), dim3(256), 0, st, *g);
   return hipGetLastError();
 }

@@ -74,6 +74,7 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                           hipEvent_t e0, hipEvent_t e1) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
+  if ((size_t)g->n_streams * RN_GRU * 4 >= (1ull << 32)) return hipErrorNotSupported;  // 32-bit offsets in nn_layers.hip
   const dim3 grid((g->n_streams + TS - 1) / TS);
   RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, e0, (hipEvent_t) nullptr, *g, *m, *tb);
   for (int k = 0; k < 3; k++) {

@@ -35,6 +35,7 @@ struct RnTablesDev {
   const uint16_t *bitrev;     // [960]   digit reversal of the 5.3.4.4.4 FFT (src/rnnoise_tables.c:10, by formula), padded position
   const uint8_t *band_of_bin; // [400]   band index i with eband[i] <= bin < eband[i+1]
   const uint32_t *rcp_lut;    // [2048]  x86 rcpps stand-in (oracle/rcp_capture.c)
+  const uint32_t *rcp_lut_b;  // [2048]  rcp_lut[i] + 0x3f800000 (mod 2^32)
   const float *fft_tw;        // [16][64][2] per-lane twiddles of the register-resident FFT (fft_reg.h: RN_FTW_*)
   const uint32_t *band_q;     // [400]  per bin: LDS slot of its (1-frac) term | slot of its frac term << 11 | band << 22
   const uint32_t *band_chain; // [34]   per band accumulator: first slot (16-byte aligned) | number of terms << 16
@@ -90,8 +91,11 @@ struct RnGroupDev {
   float *vad;          // [N]
   float *lpc2;         // [RN_RING_SLOTS][N][8] (5 used) FIR taps of rnn_pitch_downsample, produced by K0, consumed by K1
   float *nn_act;       // [N][384] conv2 output in f32 (MFMA path: input of dense_out)
-  int8_t *act_q[2];    // [ceil(N/16)][6144] layer-wise network: quantised layer input per 16-stream tile, B-fragment order
-                       //   (ping-pong: layer k reads [k & 1], writes [(k + 1) & 1]); whole batches only, never offset by views
+  int8_t *act_q[4];    // [ceil(N/16)][6144] layer-wise network: u8-quantised activations per 16-stream tile, B-fragment order:
+                       //   [0] conv2 output (scratch of the step), [1 + k] GRU state k -- at once the input of layer k + 1 and
+                       //   the recurrent operand of layer k at the NEXT frame, so the layer kernels never re-quantise the
+                       //   f32 state.  Derived data: valid only while every state change went through the layer kernels
+                       //   (RNNoiseBatch::img_valid; rn_launch_nn_requant rebuilds them).  Whole batches only, never offset by views.
   float *train_clean_mem;  // [N][480] analysis memory of the clean stream (training-feature extraction only)
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };

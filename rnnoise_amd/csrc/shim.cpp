@@ -34,6 +34,7 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, 
                                         hipEvent_t);
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                           hipEvent_t);
+extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
@@ -415,7 +416,11 @@ int tables_for_device(int device, RnTablesDev &out) {
       for (int bin = kEband[b]; bin < kEband[b + 1]; bin++)
         band_q[bin] = (uint32_t)(start[b] + bin - lo[b]) | ((uint32_t)(start[b + 1] + bin - lo[b + 1]) << 11) | ((uint32_t)b << 22);
   }
+  // the same table with the exponent bias of the reciprocal folded in (nn_layers.hip: one integer subtract less per activation)
+  std::vector<uint32_t> lut_b(2048);
+  for (int i = 0; i < 2048; i++) lut_b[i] = RN_RCP_LUT_X86[i] + 0x3f800000u;
   Staging st;
+  size_t o_lb = st.add(lut_b.data(), 4 * lut_b.size());
   size_t o_ftw = st.add(ftw.data(), 4 * ftw.size());
   size_t o_bq = st.add(band_q.data(), 4 * band_q.size()), o_bc = st.add(band_chain.data(), 4 * band_chain.size());
   size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
@@ -435,6 +440,7 @@ int tables_for_device(int device, RnTablesDev &out) {
   t.dev.band_of_bin = base + o_b;
   t.dev.bitrev = reinterpret_cast<const uint16_t *>(base + o_br);
   t.dev.rcp_lut = reinterpret_cast<const uint32_t *>(base + o_r);
+  t.dev.rcp_lut_b = reinterpret_cast<const uint32_t *>(base + o_lb);
   t.dev.fft_tw = reinterpret_cast<const float *>(base + o_ftw);
   t.dev.band_q = reinterpret_cast<const uint32_t *>(base + o_bq);
   t.dev.band_chain = reinterpret_cast<const uint32_t *>(base + o_bc);
@@ -475,6 +481,7 @@ struct RNNModel {
 struct RNNoiseBatch {
   RNNModel *model = nullptr;
   int device = 0, n = 0, nn_path = 0;
+  bool img_valid = false;  // g.act_q[1..3] mirror gru_state (rn_dev.h); cleared by whatever else writes the state
   int schedule = 0;  // 0: default (3-stream frame pipeline in multi-frame calls); 9: one stream; 1: only the high-pass aside
   int parity = 0;  // spectra slot (mod RN_SPEC_SLOTS) the next frame writes; the previous one holds the delayed spectra
   long frame_no = 0;  // selects the per-step scratch copy (features / silence / pitch are double-buffered)
@@ -732,7 +739,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.gains = carve<float>(p, RN_NB_BANDS * N);
   g.vad = carve<float>(p, N);
   g.nn_act = carve<float>(p, RN_GRU * N);
-  for (int k = 0; k < 2; k++) g.act_q[k] = carve<int8_t>(p, (N + 15) / 16 * 6144);
+  for (int k = 0; k < 4; k++) g.act_q[k] = carve<int8_t>(p, (N + 15) / 16 * 6144);
   g.lpc2 = carve<float>(p, 8 * N * RN_RING_SLOTS);
   g.train_clean_mem = carve<float>(p, RN_FRAME_SIZE * N);
   return (size_t)(p - base);
@@ -895,6 +902,7 @@ extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   if (!b) return -1;
   ON_DEVICE(b->device);
   HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
+  b->img_valid = false;
   b->parity = 0;
   b->ring_slot = 0;
   b->frame_no = 0;
@@ -1008,10 +1016,15 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     {
       TimedLaunch t(b, 1);
       const bool whole = g.n_streams == g.n_stride;  // (the layer images are indexed by tile of the whole batch)
-      if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams())))
+      if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams()))) {
+        if (!b->img_valid) HIP_OK(rn_launch_nn_requant(&g, st));
+        b->img_valid = true;
         HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, t.start(), t.stop()));
-      else if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
-      else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+      } else {
+        b->img_valid = false;
+        if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+        else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+      }
     }
     {
       TimedLaunch t(b, 2);
@@ -1222,6 +1235,7 @@ extern "C" int rnnoise_batch_import_state(RNNoiseBatch *b, int s, const float *f
   HIP_OK(hipDeviceSynchronize());
   if (!b->state_stage) HIP_OK(hipMalloc((void **)&b->state_stage, RN_STATE_FLOATS * sizeof(float)));
   H2D(b->state_stage, f, RN_STATE_FLOATS);
+  b->img_valid = false;
   const RnGroupDev v = group_view(b->g, s, 1);
   HIP_OK(rn_launch_state_scatter(&v, b->state_stage, (b->ring_slot + RN_RING_SLOTS - 1) % RN_RING_SLOTS,
                                  (b->parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS, nullptr));
