@@ -179,6 +179,10 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
 #pragma unroll
   for (int t = 0; t < GM; t++) live[t] = (tile0 + t) * TS + n < N && !sil[t];  // silent streams keep their state (src/denoise.c:474)
   const RnLinearDev &wi = m.gru_in[layer], &wr = m.gru_rec[layer];
+  // The two waves of a SIMD run the same phases from the same barrier: left alone they want the MFMA pipe together and
+  // the VALU together.  Giving one of them issue priority lets it run ahead, after which one's MFMA block overlaps the
+  // other's epilogue.
+  if (wave < GW / 2) __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
   for (int ui = 0; ui < 24 / GW; ui++) {
     const int u = wave + GW * ui, unit0 = 16 * u + 4 * gq;
