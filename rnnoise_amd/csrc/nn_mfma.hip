@@ -15,6 +15,7 @@
 // B lane l -> column (stream) l&15, k-group l>>4; C/D lane l, reg r -> row 4*(l>>4)+r, col l&15.
 // Results are bit-identical to the vector path and to the oracle.
 #include "nn_common.h"
+#include <stdlib.h>
 
 #define CHUNK 256      // inputs per staged chunk of the dense_out / vad chains
 #define CH_STRIDE 260  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
@@ -70,6 +71,7 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st);
+extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e1);
 // the same network as five launches (front, three GRU layers at 64 streams per workgroup, back); e0 / e1 bracket the lot
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                           hipEvent_t e0, hipEvent_t e1) {
@@ -81,6 +83,8 @@ extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev 
     hipError_t e = rn_launch_nn_gru_layer(g, m, tb, k, st);
     if (e != hipSuccess) return e;
   }
+  static const bool old_back = getenv("RNNOISE_AMD_NN_BACK16") != nullptr;  // A/B: the 16-stream tile kernel's dense phase
+  if (!old_back) return rn_launch_nn_dense(g, m, tb, st, e1);
   RN_LAUNCH(rn_nn_back_kernel, grid, dim3(NTHREADS), 0, st, (hipEvent_t) nullptr, e1, *g, *m, *tb);
   return hipGetLastError();
 }
