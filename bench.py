@@ -67,11 +67,26 @@ ALG_BYTES = {
 }
 KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "network": "rn_nn_mfma_kernel",
              "synthesis": "rn_synthesis_kernel"}
+NN_LAYERS_MIN_STREAMS = 16384  # shim.cpp nn_layers_min_streams(): from here up the network runs as five launches
+NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
+
+
+def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
+    """Name of the kernel behind a timed kind (rocprofv3 / PMC tables use it).  The network kind of a large batch is five
+    launches timed as one (front, three GRU layers, dense); its PMC record is that of the GRU layer kernel, which is
+    three of the five and the longest."""
+    if kind == "network":
+        if nn != "mfma":
+            return "rn_nn_vector_kernel"
+        return "rn_nn_gru_kernel" if n_streams >= NN_LAYERS_MIN_STREAMS else "rn_nn_mfma_kernel"
+    if kind == "analysis" and n_streams < 6144:
+        return "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
+    return KERNEL_OF[kind]
 
 
 def waves_per_launch(kind: str, n_streams: int) -> int:
     return {"highpass": -(-n_streams // 64), "analysis": -(-n_streams // 4) * 4 if n_streams >= 6144 else n_streams,
-            "network": -(-n_streams // 16) * 8,
+            "network": (-(-n_streams // 64) if n_streams >= NN_LAYERS_MIN_STREAMS else -(-n_streams // 16)) * 8,
             "synthesis": n_streams}[kind]
 
 
@@ -349,9 +364,7 @@ def bench_rank(a) -> dict | None:
         kinds = ("highpass", "analysis", "network", "synthesis")
         per_launch = {k: ALG_BYTES[k] * N + (W if k == "network" else 0) for k in kinds}
         dom = max(kinds, key=lambda k: kms[k])
-        kname = KERNEL_OF[dom] if (dom != "network" or a.nn == "mfma") else "rn_nn_vector_kernel"
-        if dom == "analysis" and N < 6144:
-            kname = "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
+        kname = kernel_of(dom, N, a.nn)
         ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         pmc = pmc_record(kname, N, a.model) or {}
         traffic = int(pmc["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pmc else None
@@ -382,9 +395,7 @@ def bench_rank(a) -> dict | None:
         }
         if kms_alone:
             da = max(kinds, key=lambda k: kms_alone[k])
-            na = KERNEL_OF[da] if (da != "network" or a.nn == "mfma") else "rn_nn_vector_kernel"
-            if da == "analysis" and N < 6144:
-                na = "rn_analysis_single_kernel"
+            na = kernel_of(da, N, a.nn)
             pa = pmc_record(na, N, a.model) or {}
             aa = per_launch[da] / (kms_alone[da] * 1e-3) / 1e9
             line["roofline_standalone"] = {

@@ -263,12 +263,13 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
   }
 }
 
-extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st) {
+extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
+                                             hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_gru_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, *g, *m, *tb, layer);
+  RN_LAUNCH(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer);
   return hipGetLastError();
 }
 
@@ -285,7 +286,11 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
 //   dense_out weights in MFMA A-operand order (shim.cpp: stage_linear), one piece per row tile and group of four steps.
 // No compiler-counted vector load is left in the loop: vmcnt retires in order, so a counted load issued behind a DMA piece
 // would make its consumer wait for that piece's HBM trip (first version: weights through a register ring, 132 us; the
-// chains stalled once per chunk).  vad_dense's weights are wave-uniform: scalar loads.
+// chains stalled once per chunk).
+// Measured dead ends: four / five activation chunks in flight instead of two with the fetching split by role (waves 0-3
+// activations, 4-5 weights: 134-153 us against 111); the chains run inside the GRU kernels on the state they have just
+// written to LDS, partial sums handed on through g.gains / g.vad (no dense kernel, no f32 re-read: the 96-step tails are
+// MFMA-pipe bound at 2 chains per SIMD and wait for the slowest wave: +36 us per layer, the same total).
 #define DKC 64  // inputs per staged chunk
 #define DNB 3   // chunks in LDS
 struct DenseLds {
@@ -404,9 +409,10 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_dense_kernel(RnGrou
   }
 }
 
-extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e1) {
+extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e0,
+                                         hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
-  RN_LAUNCH(rn_nn_dense_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), 0, st, (hipEvent_t) nullptr, e1, *g, *m, *tb);
+  RN_LAUNCH(rn_nn_dense_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
 

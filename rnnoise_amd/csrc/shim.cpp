@@ -32,8 +32,7 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *
                                           hipEvent_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                         hipEvent_t);
-extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
-                                          hipEvent_t);
+extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
@@ -1014,13 +1013,17 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->cur_k1[f & 7], 0));
     }
     {
-      TimedLaunch t(b, 1);
       const bool whole = g.n_streams == g.n_stride;  // (the layer images are indexed by tile of the whole batch)
       if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams()))) {
         if (!b->img_valid) HIP_OK(rn_launch_nn_requant(&g, st));
         b->img_valid = true;
-        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+        // five launches, each timed on its own (kind 1: the durations add up to the network's)
+        TimedLaunch t0(b, 1), t1(b, 1), t2(b, 1), t3(b, 1), t4(b, 1);
+        hipEvent_t ev[5][2] = {{t0.start(), t0.stop()}, {t1.start(), t1.stop()}, {t2.start(), t2.stop()}, {t3.start(), t3.stop()},
+                               {t4.start(), t4.stop()}};
+        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, ev));
       } else {
+        TimedLaunch t(b, 1);
         b->img_valid = false;
         if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
         else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));

@@ -11,10 +11,14 @@ import bench  # noqa: E402
 
 
 def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
-    for n in (1024, 4096, 16384, 65536, 524288 // 8):
-        for k in ("rn_hp_kernel", "rn_analysis_kernel", "rn_analysis_single_kernel", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
+    for n in (1024, 4096, 8192, 16384, 65536, 524288 // 8):
+        names = [bench.kernel_of(kind, n) for kind in ("highpass", "analysis", "network", "synthesis")]
+        assert names[2] == ("rn_nn_gru_kernel" if n >= 16384 else "rn_nn_mfma_kernel")  # five launches from 16,384 streams up
+        for k in names + ["rn_analysis_kernel", "rn_analysis_single_kernel"]:
             r = bench.pmc_record(k, n)
             assert r and r["hbm_bytes_per_frame"] > 1000 and r["valu_per_wave"] > 100, (k, n, r)
+    for k in bench.NN_LAYER_KERNELS:  # every launch of the layer-wise network has its own PMC record
+        assert bench.pmc_record(k, 65536)["hbm_bytes_per_frame"] > 1000, k
     assert bench.pmc_record("rn_nn_vector_kernel", 4096) is None  # never profiled with PMC: traffic is reported as null
 
 
@@ -22,7 +26,7 @@ def test_algorithmic_bytes_match_design_table():
     # DESIGN.md section 4
     assert bench.ALG_BYTES == {"highpass": 10788, "analysis": 26164, "network": 12696, "synthesis": 14352}
     assert bench.waves_per_launch("analysis", 65536) == 65536 and bench.waves_per_launch("highpass", 65536) == 1024
-    assert bench.waves_per_launch("network", 65536) == 4096 * 8 and bench.waves_per_launch("network", 17) == 16
+    assert bench.waves_per_launch("network", 65536) == 1024 * 8 and bench.waves_per_launch("network", 17) == 16
 
 
 def test_defaults_are_the_largest_single_gpu_config():
@@ -67,7 +71,8 @@ def test_committed_bench_lines_follow_the_contract():
         # numerator and denominator of the roofline cover the same kernel (round-1 ADVICE): its own bytes / its own time
         r = d["roofline"]
         kind = {"rn_hp_kernel": "highpass", "rn_analysis_kernel": "analysis", "rn_analysis_single_kernel": "analysis",
-                "rn_nn_mfma_kernel": "network", "rn_nn_vector_kernel": "network", "rn_synthesis_kernel": "synthesis"}[r["kernel"]]
+                "rn_nn_mfma_kernel": "network", "rn_nn_gru_kernel": "network", "rn_nn_vector_kernel": "network",
+                "rn_synthesis_kernel": "synthesis"}[r["kernel"]]
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"][kind] * 1e-3) / 1e9) < 0.02 * r["achieved"]
         if d["n_gpus"] == 1 and "cpu_baseline" in d:
             cb = d["cpu_baseline"]
@@ -78,5 +83,6 @@ def test_committed_bench_lines_follow_the_contract():
 def test_rocprof_summary_lists_the_kernels_of_the_step():
     for f in ["r1_final_kernel_stats.txt"] + [os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r2_*kernel_stats*.txt"))]:
         txt = open(os.path.join(ROOT, "profiles", f)).read()
-        for k in ("rn_hp_kernel", "rn_analysis", "rn_nn_mfma_kernel", "rn_synthesis_kernel"):
+        nn = ("rn_nn_mfma_kernel",) if f.startswith("r1_") else ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
+        for k in ("rn_hp_kernel", "rn_analysis", "rn_synthesis_kernel") + nn:
             assert k in txt, (f, k)

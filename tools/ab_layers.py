@@ -28,8 +28,8 @@ for n in () if SERIAL else (70, 16, 129):
         res.append(b.process(pcm) + (b.export_state(n - 1),))
         b.close()
     ok = all(np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32)) for a, c in zip(res[0][:3], res[1][:3]))
-    ok = ok and res[0][3] == res[1][3]
-    print(f"n={n}: layer-wise == fused: {ok}")
+    ok = bool(ok) and bool(np.array_equal(np.asarray(res[0][3]), np.asarray(res[1][3])))
+    print(f"n={n}: layer-wise == fused (pcm, vad, gains, state of the last stream): {ok}")
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cap = 8

@@ -15,7 +15,8 @@ python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 > "$O/b.lo
 python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 > "$O/b.log" 2>&1;          last "$O/b.log" > "$O/bench_16384.json"
 python "$R/bench.py" --no-cpu-baseline --host-io --steps 8 --warmup 2 --repeats 9 > "$O/b.log" 2>&1;     last "$O/b.log" > "$O/bench_hostio_65536.json"
 python "$R/tools/serial_times.py" 4096 16384 65536 2>&1 | grep "N=" > "$O/serial_times.txt"
-python "$R/tools/k1_cycles.py" 65536 --nn 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
+RNNOISE_AMD_NN_LAYERS_MIN=100000000 python "$R/tools/ab_layers.py" 65536 2>&1 | grep -E "^N=|^n=" > "$O/network_schedules_65536.txt"
+python "$R/tools/k1_cycles.py" 65536 --nn --layers 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
 python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"
 python "$R/tools/fft_bench.py" 2>&1 | grep -v amdgpu.ids > "$O/fft_bench.txt"
 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline --repeats 5 > "$O/trace.log" 2>&1

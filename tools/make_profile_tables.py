@@ -16,7 +16,7 @@ pre = sys.argv[3] if len(sys.argv) > 3 else "r2"
 for n in ("bench_65536", "bench_4096", "bench_4096_vector", "bench_16384", "bench_little_32768", "bench_hostio_65536"):
     if os.path.exists(os.path.join(src, n + ".json")) and os.path.getsize(os.path.join(src, n + ".json")) > 10:
         shutil.copy(os.path.join(src, n + ".json"), os.path.join(dst, f"{pre}_{n}.json"))
-for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench"):
+for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench", "network_schedules_65536"):
     if os.path.exists(os.path.join(src, n + ".txt")):
         shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
