@@ -266,9 +266,16 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
                                              hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_gru_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
-  if (attr != hipSuccess) return attr;
+  // more than 64 KB of LDS is an opt-in, per device (a process may hold batches on several GPUs)
+  static bool opted[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!opted[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_gru_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
+    if (attr != hipSuccess) return attr;
+    opted[dev] = true;
+  }
   RN_LAUNCH(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer);
   return hipGetLastError();
 }

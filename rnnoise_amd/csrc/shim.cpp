@@ -1013,7 +1013,8 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
       if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->cur_k1[f & 7], 0));
     }
     {
-      const bool whole = g.n_streams == g.n_stride;  // (the layer images are indexed by tile of the whole batch)
+      // (the layer images are indexed by tile of the whole batch; the layer kernels use 32-bit byte offsets into a state plane)
+      const bool whole = g.n_streams == g.n_stride && (size_t)g.n_streams * RN_GRU * 4 < (1ull << 32);
       if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams()))) {
         if (!b->img_valid) HIP_OK(rn_launch_nn_requant(&g, st));
         b->img_valid = true;
