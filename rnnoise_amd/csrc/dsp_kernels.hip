@@ -1013,9 +1013,13 @@ rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnT
 
 
 struct SynthLds {
-  cpx S[RN_WINDOW_SIZE];  // Hermitian-extended spectrum in natural order (staging for the transform); band products before that
+  float S[1052];  // band products (RnTablesDev::band_q slots); then the Hermitian-extended spectrum in natural order, the real
+                  // parts and the imaginary parts one after the other (staging for the transform)
   float misc[192];
 };
+// 4,976 B: two of these waves fit into the LDS that four analysis workgroups (4 x 38,016 B) leave free on a CU -- with the
+// complex spectrum staged in one piece (8,448 B) it was one, and synthesis mostly waited for analysis workgroups to drain
+static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052, "synthesis LDS");
 
 // ---------------------------------------------------------------------------------------------
 // K3: rnn_pitch_filter + gain smoothing/interpolation + frame_synthesis
@@ -1024,7 +1028,7 @@ struct SynthLds {
 // through the band stages; every HBM operand is requested before the first dependent instruction, so the wave pays one
 // memory round trip instead of one per stage.  The inverse transform is the register-resident FFT of fft_reg.h: the
 // Hermitian-extended spectrum passes once through LDS (natural order in, 15 consecutive bins out per lane) and the time
-// samples come out in registers, lane l holding work-area positions 64*blk + p.  7.8 KB of LDS per wave.
+// samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity, int prev) {
@@ -1036,7 +1040,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
   const float *cE = g.spec_E[parity] + (size_t)s * 96;
   float *r = L.misc + 0, *gsm = L.misc + 32, *newE = L.misc + 64, *norm = L.misc + 96, *sums = L.misc + 128;
-  float *Q = reinterpret_cast<float *>(L.S);
+  float *Q = L.S;
   const int silence = g.silence[s];
   constexpr int NBIN = 8;  // bins pos + 64*j
 
@@ -1128,25 +1132,26 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   }
 #undef INTERP
 #undef BAND
-  // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT.  Natural order into LDS ...
-#pragma unroll
-  for (int j = 0; j < NBIN; j++) {
-    const int bin = pos + WAVE * j;
-    if (bin < RN_FREQ_SIZE) {
-      L.S[bin] = {0.0010416667f * X[j].x, 0.0010416667f * X[j].y};
-      if (bin > 0 && bin < RN_FREQ_SIZE - 1) L.S[RN_WINDOW_SIZE - bin] = {0.0010416667f * X[j].x, 0.0010416667f * (-X[j].y)};
-    }
-  }
-  RN_WSYNC();
-  // ... and this lane's 15 consecutive bins out of it (fft_reg.h "Input")
+  // inverse_transform (src/denoise.c:200-217): Hermitian extension through the FORWARD FFT.  Natural order into LDS and
+  // this lane's 15 consecutive bins out of it (fft_reg.h "Input"): first the real parts, then the imaginary parts
   float yr[15], yi[15];
   {
-    const cpx *run = L.S + 15 * fft_lam(lane);
+    const float *run = L.S + 15 * fft_lam(lane);
 #pragma unroll
-    for (int b = 0; b < 15; b++) {
-      const cpx v = run[fft_c(b)];
-      yr[b] = v.r;
-      yi[b] = v.i;
+    for (int part = 0; part < 2; part++) {
+#pragma unroll
+      for (int j = 0; j < NBIN; j++) {
+        const int bin = pos + WAVE * j;
+        if (bin < RN_FREQ_SIZE) {
+          const float v = 0.0010416667f * (part ? X[j].y : X[j].x);
+          L.S[bin] = v;
+          if (bin > 0 && bin < RN_FREQ_SIZE - 1) L.S[RN_WINDOW_SIZE - bin] = part ? 0.0010416667f * (-X[j].y) : v;
+        }
+      }
+      RN_WSYNC();
+#pragma unroll
+      for (int b = 0; b < 15; b++) (part ? yi : yr)[b] = run[fft_c(b)];
+      RN_WSYNC();
     }
   }
   regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));

@@ -307,6 +307,47 @@ def test_reset_restores_initial_state(model):
     assert not a[0][0].any()  # first output frame is all zeros
 
 
+def test_layerwise_network_survives_state_surgery(model, blob_default):
+    """the layer-wise schedule keeps u8 images of the GRU state between frames (rn_dev.h: act_q); whatever else writes the
+    state -- import, reset, a step on the other network kernels -- must invalidate them.  70 streams = ragged tile + ragged
+    64-stream group."""
+    n, T = 70, 24
+    ids = [(5 * s) % 13 for s in range(n)]
+    pcm = synth.batch_pcm(ids, T)
+    pcm[9:12, 3::7] = 0                                   # silent gaps: a frozen state keeps its image, too
+    want = {i: Oracle(blob_default).run(pcm[:, ids.index(i)]) for i in sorted(set(ids)) if ids.index(i) % 7 != 3}
+    b = capi.Batch(model, n)
+    b.set_nn_path(2)
+    out1, _, g1 = b.process(pcm[:8])
+    st = [b.export_state(s) for s in (0, 17, 69)]
+    out2, _, g2 = b.process(pcm[8:16])
+    # a second batch takes over three of the streams in the middle of the sequence
+    b2 = capi.Batch(model, n)
+    b2.set_nn_path(2)
+    b2.process(pcm[:3])                                    # its own images are now valid for OTHER states
+    for k, s in enumerate((0, 17, 69)):
+        b2.import_state(s, st[k])
+    o2b, _, g2b = b2.process(pcm[8:16])
+    for s in (0, 17, 69):
+        assert_bits_equal(o2b[:, s], out2[:, s], f"pcm of stream {s} after import")
+        assert_bits_equal(g2b[:, s], g2[:, s], f"gains of stream {s} after import")
+    # one step on the tile kernel in between, then layer-wise again
+    b.set_nn_path(1)
+    out3a, _, g3a = b.process(pcm[16:17])
+    b.set_nn_path(2)
+    out3b, _, g3b = b.process(pcm[17:])
+    got_out = np.concatenate([out1, out2, out3a, out3b])
+    got_g = np.concatenate([g1, g2, g3a, g3b])
+    for s, i in enumerate(ids):
+        if s % 7 != 3 and ids.index(i) == s:
+            assert_bits_equal(got_out[:, s], want[i]["out"], f"pcm stream {s}")
+            assert_bits_equal(got_g[:, s], want[i]["gains"], f"gains stream {s}")
+    b.reset()
+    o, _, g = b.process(pcm[:8])
+    assert_bits_equal(o, out1, "after reset")
+    assert_bits_equal(g, g1, "gains after reset")
+
+
 def test_drop_in_single_stream_api(model, blob_default):
     """rnnoise_create / rnnoise_process_frame (in place, like examples/rnnoise_demo.c:57) / destroy"""
     T = 30
