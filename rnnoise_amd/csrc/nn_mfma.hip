@@ -66,7 +66,7 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_back_kernel(RnGroup
 
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                         hipEvent_t e0, hipEvent_t e1) {
-  if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm) return hipErrorNotSupported;
+  if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm) return hipErrorNotSupported;
   RN_LAUNCH(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
@@ -78,7 +78,7 @@ extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *
 // (start, stop) events of launch i: each kernel is timed on its own, the five durations add up to the network's
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                           hipEvent_t ev[5][2]) {
-  if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
+  if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
   if ((size_t)g->n_streams * RN_GRU * 4 >= (1ull << 32)) return hipErrorNotSupported;  // 32-bit offsets in nn_layers.hip
   const dim3 grid((g->n_streams + TS - 1) / TS);
   RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
