@@ -307,6 +307,62 @@ def test_reset_restores_initial_state(model):
     assert not a[0][0].any()  # first output frame is all zeros
 
 
+@pytest.mark.parametrize("path", [0, 2])
+def test_extreme_but_finite_inputs(model, blob_default, path):
+    """the corners of the input domain the reference's own callers can reach: full-scale square waves, samples far outside
+    the int16 range, a large DC offset, isolated impulses, amplitudes down in the denormal range (nothing flushes to zero:
+    the x86 build runs without FTZ/DAZ), exact digital silence between bursts"""
+    T = 30
+    n = T * 480
+    t = np.arange(n)
+    rng = np.random.default_rng(5)
+    sig = [
+        32767.0 * np.sign(np.sin(2 * np.pi * 440 * t / 48000) + 1e-9),                 # full-scale square
+        3.0e6 * np.sin(2 * np.pi * 233 * t / 48000),                                    # 100x beyond int16
+        30000.0 + 2000.0 * rng.standard_normal(n),                                      # DC offset + noise
+        np.where(t % 997 == 0, 32768.0, 0.0) - np.where(t % 1499 == 0, 32768.0, 0.0),   # impulses in silence
+        1e-38 * rng.standard_normal(n),                                                 # denormal products all along the path
+        np.where((t // 4800) % 2 == 0, 8000.0 * np.sin(2 * np.pi * 150 * t / 48000), 0.0),  # bursts / exact zeros
+        1e-3 * rng.standard_normal(n),                                                  # just above the silence threshold
+    ]
+    ids = list(range(len(sig))) * 3                                                      # 21 streams: a full tile and a ragged one
+    pcm = np.stack([sig[i].astype(np.float32).reshape(T, 480) for i in ids], axis=1)
+    b = capi.Batch(model, len(ids))
+    b.set_nn_path(path)
+    out, vad, gains = b.process(pcm)
+    assert np.isfinite(out).all()
+    for i in range(len(sig)):
+        want = Oracle(blob_default).run(pcm[:, i])
+        for s in (i, i + len(sig), i + 2 * len(sig)):
+            assert_bits_equal(out[:, s], want["out"], f"pcm, signal {i}, stream {s}")
+            assert_bits_equal(gains[:, s], want["gains"], f"gains, signal {i}")
+            assert_bits_equal(vad[:, s], want["vad"], f"vad, signal {i}")
+    b.close()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_a_poisoned_stream_stays_alone(model, blob_default, path):
+    """NaN / Inf samples in one stream of an MFMA tile (garbage in: its own output is not specified) must not reach its
+    15 tile-mates or anybody else: streams share kernels, tiles and workgroups, never data"""
+    T, n, bad = 12, 40, 21
+    pcm = synth.batch_pcm([s % 9 for s in range(n)], T)
+    pcm[3, bad, 100] = np.nan
+    pcm[5, bad, 7] = np.inf
+    pcm[6, bad, 300:320] = -np.inf
+    b = capi.Batch(model, n)
+    b.set_nn_path(path)
+    out, vad, gains = b.process(pcm)
+    cache = {}
+    for s in range(n):
+        if s == bad:
+            continue
+        if s % 9 not in cache:
+            cache[s % 9] = Oracle(blob_default).run(pcm[:, s])
+        assert_bits_equal(out[:, s], cache[s % 9]["out"], f"pcm of stream {s}")
+        assert_bits_equal(gains[:, s], cache[s % 9]["gains"], f"gains of stream {s}")
+    b.close()
+
+
 def test_layerwise_network_survives_state_surgery(model, blob_default):
     """the layer-wise schedule keeps u8 images of the GRU state between frames (rn_dev.h: act_q); whatever else writes the
     state -- import, reset, a step on the other network kernels -- must invalidate them.  70 streams = ragged tile + ragged
