@@ -977,6 +977,13 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     // completion events ride in the dispatch packets (stop event of hipExtLaunchKernel): no record packets between
     // the kernels of a stream
     if (pipelined && f >= 3) HIP_OK(hipStreamWaitEvent(sc, b->cur_k1[(f - 3) & 7], 0));
+    // ... and not before synthesis(f-4) is done, which is when analysis(f-2) starts: left to the ring alone, the high-pass
+    // starts the moment analysis(f-3) ends -- together with the GRU layer kernels of frame f-4.  Its 1024 waves are one per
+    // SIMD for 0.18 ms, and a GRU workgroup (2 waves x 240 VGPRs per SIMD) does not fit beside even one of them: the first
+    // layer kernel of every frame waited that long (rocprofv3 timeline: 283 us instead of 115).  Beside the analysis kernel
+    // (4 waves x 56 VGPRs per SIMD) it costs nothing.
+    static const bool hp_early = getenv("RNNOISE_AMD_HP_EARLY") != nullptr;  // A/B runs only: the ring-bound start
+    if (side_k1 && f >= 4 && !hp_early) HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[(f - 4) & 7], 0));
     TimedLaunch t(b, 3);
     b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
     HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
