@@ -994,7 +994,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 // (4 waves per SIMD is what the LDS allows: 16 arenas of 10 KB per CU; without the cap the allocator spreads to 154 VGPRs)
 extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
-  analysis_body<false, K1_SPW>(g, tb, slot, parity, RnTrainArgs{});
+  // Above the high-pass kernel's waves (priority 0), which run beside this kernel two frames ahead and are in no hurry:
+  // one of them per SIMD, always ready with an old instruction, otherwise takes issue slots from four analysis waves
+  // (29.14 -> 29.41 M frames/s at 65,536 streams; RNNOISE_AMD_K1_PRIO=0 switches it off for A/B runs).
+  if (slot & 256) __builtin_amdgcn_s_setprio(1);
+  analysis_body<false, K1_SPW>(g, tb, slot & 255, parity, RnTrainArgs{});
 }
 // One stream per workgroup: batches that fit in one round of resident waves (<= 16 per CU) are bound by a wave's latency,
 // not by instruction issue, and there the narrow phases are better run by every wave for itself.  Measured on MI355X
@@ -1230,7 +1234,8 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1, st, e0, e1, *g, *tb, slot, parity);
   } else {
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot, parity);
+    static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio, parity);
   }
   return hipGetLastError();
 }
