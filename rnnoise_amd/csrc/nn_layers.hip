@@ -1,11 +1,16 @@
-// nn_layers.hip -- K2 for large batches: one GRU layer (src/nnet.c:65-94) for 64 streams per workgroup.
+// nn_layers.hip -- K2 for large batches (from 16,384 streams up, shim.cpp: nn_layers_min_streams): the network layer by layer.
+//
+//   rn_nn_front_kernel (nn_mfma.hip)  conv1, conv2 per 16-stream tile; leaves the u8 image of the conv2 output in act_q[0]
+//   rn_nn_gru_kernel    x 3           one GRU layer (src/nnet.c:65-94) for 64 streams per workgroup
+//   rn_nn_dense_kernel                dense_out + vad_dense (src/rnn.c:53-58) for 64 streams per workgroup
+//   rn_nn_requant_kernel              rebuilds the state images after anything else wrote the GRU state
 //
 // The fused tile kernel (nn_mfma.hip) walks all seven int8 matrices for 16 streams: every weight fragment a wave
-// fetches from L2 feeds ONE MFMA, and its phases are latency-bound (rocprof: 61-66 % of wave time waiting).  Here
-// a workgroup holds the quantised inputs of GM = 4 tiles in LDS and every weight fragment feeds four MFMAs, one per
-// tile: a quarter of the L2 weight traffic per stream, four independent accumulator chains per wave.  The layer's input
-// arrives as the B-fragment image the previous launch left in HBM (act_q), its output leaves the same way.
-// Arithmetic per element is the fused kernel's, so the bits are too (tests/test_gpu_parity.py runs both).
+// fetches from L2 feeds ONE MFMA, and its phases are latency-bound (rocprof: 61-66 % of wave time waiting).  Here a GRU
+// workgroup holds the quantised inputs of GM = 4 tiles in LDS and works on 3 gates x 4 tiles per weight fragment.  A
+// layer's input arrives as the B-fragment image the previous launch left in HBM (RnGroupDev::act_q), its output -- at
+// once the next layer's input and this layer's recurrent operand of the next frame -- leaves the same way.
+// Arithmetic per element is the fused kernel's, so the bits are too (tests/test_gpu_parity.py runs both; tools/ab_layers.py).
 #include "nn_common.h"
 
 #define GM 4  // 16-stream tiles per workgroup
@@ -23,14 +28,8 @@ struct GruLds {
 };
 static_assert(sizeof(GruLds) <= 160 * 1024, "one workgroup per CU, all of its LDS");
 
-// acc[gate][t] += W(row tile 24 gate + u) . image[t]: the three gates of a unit tile share the layer input, so one B
-// fragment read from LDS feeds three MFMAs and one A fragment from L2 four.  (Measured with the 1 x 4 blocking of the
-// first version: a 16x16x64 MFMA takes 16 cycles on its SIMD, its 1 KB B fragment 8 cycles of the CU's one LDS port --
-// four SIMDs re-reading B per MFMA are LDS-bound at half the MFMA rate.)
-// Addressing is (uniform base, unsigned 32-bit offset) throughout this file: the SGPR-base + VGPR-offset form of global_load.
-// The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
-// boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
-// (uniform base, unsigned 32-bit BYTE offset): the form the compiler turns into global_load ..., v_off, s[base:base+1]
+// Addressing in the GRU kernel is (uniform base, unsigned 32-bit BYTE offset): one VGPR per address instead of a 64-bit
+// pair per pointer (rn_launch_nn_layers refuses batches whose state plane exceeds 4 GB)
 template <typename T>
 __device__ __forceinline__ T ldg(const void *base, unsigned byte_off) {
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
@@ -93,6 +92,12 @@ __device__ __forceinline__ void dma_1k(const void *gsrc, unsigned lds_dst) {
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
+// acc[gate][t] += W(row tile 24 gate + u) . image[t]: the three gates of a unit tile share the layer input, so one B
+// fragment read from LDS feeds three MFMAs and one A fragment from L2 four.  (Measured with the 1 x 4 blocking of the
+// first version: a 16x16x64 MFMA takes 16 cycles on its SIMD, its 1 KB B fragment 8 cycles of the CU's one LDS port --
+// four SIMDs re-reading B per MFMA are LDS-bound at half the MFMA rate.)
+// The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
+// boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
 #define AD 2
 struct AFrags {
   v4i f[AD + 1][3];

@@ -46,7 +46,7 @@ __device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt,
 
 // MODE 0: the whole network for one tile.  Large batches run it layer by layer instead (nn_layers.hip): MODE 1 = the
 // front (conv1, conv2; leaves the quantised conv2 output as a B-fragment image in act_q[0]), then three launches of the
-// 64-stream GRU layer kernel, then MODE 2 = dense_out / vad_dense on the f32 activations the others left in HBM.
+// 64-stream GRU layer kernel, then the 64-stream dense kernel on the f32 activations the others left in HBM.
 extern "C" __global__ void __launch_bounds__(NTHREADS)  // (forcing <=128 VGPRs for 4 WGs/CU spills and is slower: measured)
 rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 #define RN_NN_MODE 0
@@ -58,12 +58,6 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_front_kernel(RnGrou
 #include "nn_tile_body.inc"
 #undef RN_NN_MODE
 }
-extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_back_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
-#define RN_NN_MODE 2
-#include "nn_tile_body.inc"
-#undef RN_NN_MODE
-}
-
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                         hipEvent_t e0, hipEvent_t e1) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm) return hipErrorNotSupported;
