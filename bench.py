@@ -90,6 +90,27 @@ def waves_per_launch(kind: str, n_streams: int) -> int:
             "synthesis": n_streams}[kind]
 
 
+def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma"):
+    """VALU issue time of one frame step if every SIMD issued back to back: over the step's kernels, waves x VALU instructions
+    per wave x the measured clocks per instruction (profiles/pmc_by_streams.json), spread over 1024 SIMDs at 2.4 GHz.
+    None when a kernel of the step has no PMC record (the vector network path)."""
+    n = n_streams
+    launches = [("rn_hp_kernel", -(-n // 64)), (kernel_of("analysis", n, nn), n), ("rn_synthesis_kernel", n)]
+    if nn != "mfma":
+        return None
+    if n >= NN_LAYERS_MIN_STREAMS:
+        launches += [("rn_nn_front_kernel", -(-n // 16) * 8), ("rn_nn_gru_kernel", 3 * (-(-n // 64)) * 8), ("rn_nn_dense_kernel", -(-n // 64) * 8)]
+    else:
+        launches += [("rn_nn_mfma_kernel", -(-n // 16) * 8)]
+    cycles = 0.0
+    for kernel, waves in launches:
+        r = pmc_record(kernel, n, model)
+        if not r or "valu_per_wave" not in r:
+            return None
+        cycles += waves * r["valu_per_wave"] * r.get("valu_cycles_per_inst", 4)
+    return 1e3 * cycles / N_SIMD / CLOCK_HZ
+
+
 def load_blob(name: str = "default") -> bytes:
     with open(os.path.join(ROOT, "tests", "golden", f"{name}.blob.xz"), "rb") as f:
         return lzma.decompress(f.read())
@@ -421,6 +442,16 @@ def bench_rank(a) -> dict | None:
             line["roofline_valu"] = {"bound": "valu-issue", "kernel": kname, "valu_insts_per_wave": pmc["valu_per_wave"],
                                      "waves": waves_per_launch(dom, N), "issue_bound_ms": round(1e3 * t_issue, 4),
                                      "frac": round(t_issue / (kms[dom] * 1e-3), 4), "source": pmc.get("source", "profiles/")}
+        try:  # the whole step against VALU issue: every kernel of it is issue-bound to first order
+            vi = step_valu_issue_ms(N, a.model, a.nn)
+            if vi and med > 0:
+                line["roofline_step_valu"] = {"bound": "valu-issue", "issue_bound_ms": round(vi, 4),
+                                              "frac": round(vi / (1e3 * med / K), 4),
+                                              "definition": "sum over the step's kernels of waves x VALU instructions per wave x measured "
+                                                            "clocks per instruction (PMC passes under profiles/), over 1024 SIMDs at 2.4 GHz, "
+                                                            "divided by ms_per_step"}
+        except Exception:
+            pass
         if stub:
             line["stub"] = True
         if world == 1 and not a.no_cpu_baseline and not stub:

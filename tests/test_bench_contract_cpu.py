@@ -29,6 +29,16 @@ def test_algorithmic_bytes_match_design_table():
     assert bench.waves_per_launch("network", 65536) == 1024 * 8 and bench.waves_per_launch("network", 17) == 16
 
 
+def test_step_valu_issue_bound_from_the_pmc_tables():
+    """bench.py's roofline_step_valu: the step's kernels x their measured VALU instruction counts; 65,536 streams on the
+    layer-wise network come to 1.4 ms of pure issue time, the vector path has no PMC record"""
+    v = bench.step_valu_issue_ms(65536)
+    assert 1.2 < v < 1.7, v
+    assert abs(bench.step_valu_issue_ms(32768, "little") / v - 0.5) < 0.05
+    assert 0.05 < bench.step_valu_issue_ms(4096) < 0.2
+    assert bench.step_valu_issue_ms(4096, "default", "vector") is None
+
+
 def test_defaults_are_the_largest_single_gpu_config():
     a = bench.parse_args([])
     assert a.streams == 65536 and a.gpus == 1 and a.repeats >= 25 and a.nn == "mfma" and a.model == "default"
