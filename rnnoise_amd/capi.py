@@ -105,6 +105,18 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
 
 
+def _close_quietly(obj):
+    """__del__ helper: at interpreter shutdown this module's globals (and possibly the HIP runtime the handle lives in)
+    are already gone -- the process exit reclaims the rest; anywhere else a destructor must not raise."""
+    try:
+        import sys as _sys
+        if _sys is None or _sys.is_finalizing():
+            return
+        obj.close()
+    except Exception:
+        pass
+
+
 class Model:
     """RNNModel from a "DNNw" weight blob (reference: rnnoise_model_from_buffer, rnnoise.h:102)."""
 
@@ -137,7 +149,7 @@ class Model:
             self.h = None
 
     def __del__(self):
-        self.close()
+        _close_quietly(self)
 
 
 class Batch:
@@ -156,7 +168,7 @@ class Batch:
             self.h = None
 
     def __del__(self):
-        self.close()
+        _close_quietly(self)
 
     def reset(self):
         if lib().rnnoise_batch_reset(self.h):
@@ -274,4 +286,4 @@ class DenoiseState:
             self.h = None
 
     def __del__(self):
-        self.close()
+        _close_quietly(self)

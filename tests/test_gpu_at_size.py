@@ -92,7 +92,8 @@ m = capi.Model(blob); b = capi.Batch(m, 48, device=0); b.set_nn_path(1)
 for rep in range(3):
     b.reset()
     out, vad, gains = b.process(pcm)
-print("CRC", zlib.crc32(out.tobytes()), zlib.crc32(gains.tobytes()), zlib.crc32(vad.tobytes()))
+print("CRC", zlib.crc32(out.tobytes()), zlib.crc32(gains.tobytes()), zlib.crc32(vad.tobytes()), flush=True)
+b.close(); m.close()
 """
 
 
