@@ -27,6 +27,18 @@ typedef struct RNNoiseBatch RNNoiseBatch;
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 RNNOISE_EXPORT int rnnoise_amd_device_count(void);
 
+/* The reference's x86 tanh / sigmoid divide through `rcpps` (src/vec_avx.h:413,442,484,505), whose low bits depend on
+ * the CPU family: its output is a function of the host it runs on.  The library reproduces one family at a time from a
+ * 4096-entry table (rnnoise_amd/csrc/rcp_profiles.h):
+ *   "host"      (default, alias "auto") the table is captured from the CPU this process runs on, so the bits are those the
+ *               reference library produces on this same machine;
+ *   "intel"     Intel Xeon (the committed goldens);  "amd-zen5" (alias "amd")  AMD EPYC 9005.
+ * Process-wide: $RNNOISE_AMD_RCP_PROFILE at first use, or this call at any time (devices are drained and their table
+ * replaced; every model and batch follows).  0, or -1 for an unknown name.  rnnoise_amd_rcp_profile() names the active
+ * profile: "intel", "amd-zen5", "host=intel", "host=amd-zen5", "host=captured" (a CPU whose table equals neither). */
+RNNOISE_EXPORT int rnnoise_amd_set_rcp_profile(const char *name);
+RNNOISE_EXPORT const char *rnnoise_amd_rcp_profile(void);
+
 /* Create N zero-initialised streams on `device`, all using `model` (must outlive the
  * batch, like rnnoise_create()).  NULL on error (no GPU, bad model, out of memory).
  * model==NULL fails here (the drop-in entry points rnnoise_create / rnnoise_init fall back
@@ -103,21 +115,6 @@ RNNOISE_EXPORT int rnnoise_batch_train_features_device(RNNoiseBatch *b, float *d
 /* Test taps for the last processed frame step: per-stream feature vectors [N][65],
  * silence flags [N] and final pitch periods [N] (host buffers, any may be NULL). */
 RNNOISE_EXPORT int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *silence, int *pitch);
-
-/* Pitch-analysis stage taps ([N][RN_DBG_FLOATS], layout rn_layout.h RN_DBG_*).  The first
- * call arms the taps (dst may be NULL); later calls copy the last step's record. Tests only. */
-RNNOISE_EXPORT int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst);
-
-/* Test tap: n independent 960-point transforms through the register-resident FFT of the analysis / synthesis kernels
- * (rnnoise_amd/csrc/fft_reg.h; reference: rnn_fft_c, src/kiss_fft.c:566-586), `reps` passes each with the spectrum fed
- * back as the next input.  in/out: [n][960][2] host floats, natural order.  variant 0/1 = exchange implementation.
- * clocks[n] (optional): shader clocks per wave; xlane[2][6][64] (optional): source lanes of the exchange primitives. */
-RNNOISE_EXPORT int rnnoise_amd_debug_fft(int device, int variant, float *out, const float *in, int n, int reps,
-                                         unsigned long long *clocks, int *xlane);
-
-/* Test tap: out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on `device` (src/denoise.c:383 is the one libm call
- * of the path whose device implementation differs from the host's). Host buffers. 0 / -1. */
-RNNOISE_EXPORT int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n);
 
 /* Average device time per launch of each kernel over the calls since the last query, in
  * milliseconds, measured with HIP events on the launch stream when timing is enabled.

@@ -41,10 +41,23 @@ def _fp(a: np.ndarray):
 def build_oracle() -> str:
     """Compile liboracle.so if missing or stale (gcc only; works on the GPU box too)."""
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("rn_oracle.c", "rn_oracle.h", "../rnnoise_amd/csrc/rcp_lut_x86.h")]
+    srcs = [os.path.join(HERE, f) for f in ("rn_oracle.c", "rn_oracle.h", "../rnnoise_amd/csrc/rcp_profiles.h", "../rnnoise_amd/csrc/rcp_profile_intel.h",
+                                              "../rnnoise_amd/csrc/rcp_profile_amd_zen5.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
+
+
+def set_rcp_profile(name: str) -> None:
+    """which CPU family's `rcpps` the ORACLE's tanh / sigmoid use (rnnoise_amd/csrc/rcp_profiles.h): "intel" (default:
+    the committed goldens), "amd-zen5", or "host" = captured from the CPU this process runs on, which is what a live
+    comparison against the compiled reference (oracle/_ref) or the product's default profile needs"""
+    if Oracle.lib().rno_set_rcp_profile(name.encode()) != 0:
+        raise ValueError(f"oracle: unknown or uncapturable rcp profile {name!r}")
+
+
+def rcp_profile() -> str:
+    return ("intel", "amd-zen5", "other")[Oracle.lib().rno_rcp_profile_id()]
 
 
 class _FrameRunner:
@@ -99,6 +112,7 @@ class Oracle(_FrameRunner):
             for f in ("rno_rcp", "rno_tanh", "rno_sigmoid"):
                 getattr(L, f).restype = C.c_float
                 getattr(L, f).argtypes = [C.c_float]
+            L.rno_set_rcp_profile.argtypes = [C.c_char_p]
             L.rno_quantize_u8.argtypes = [C.POINTER(C.c_ubyte), C.POINTER(C.c_float), C.c_int]
             L.rno_log_energy.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
             cls._lib = L

@@ -18,7 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "rcp_lut_x86.h"
+#include "rcp_profiles.h"
 
 #define NB RN_NB_BANDS
 #define NFREQ RN_FREQ_SIZE
@@ -659,12 +659,31 @@ void rno_model_free(RnoModel *m) {
   free(m);
 }
 
-/* rcpps stand-in, see rcp_lut_x86.h (src/vec_avx.h:413,442 use _mm256_rcp_ps) */
+/* rcpps stand-in, see rcp_profiles.h (src/vec_avx.h:413,442 use _mm256_rcp_ps; :484,505 _mm_rcp_ps).  The profile is
+   process-wide: "intel" (default here: the committed goldens were made on the Intel build host), "amd-zen5", or "host"
+   = captured from the CPU the oracle runs on, which is what a live comparison against oracle/_ref needs. */
+static unsigned short rcp_host_table[RN_RCP_ENTRIES];
+static const unsigned short *rcp_table = RN_RCP16_INTEL;
+int rno_set_rcp_profile(const char *name) {
+  if (!strcmp(name, "intel")) rcp_table = RN_RCP16_INTEL;
+  else if (!strcmp(name, "amd-zen5")) rcp_table = RN_RCP16_AMD_ZEN5;
+  else if (!strcmp(name, "host")) {
+    if (rn_rcp_capture_host(rcp_host_table)) return -1;
+    rcp_table = rcp_host_table;
+  } else return -1;
+  return 0;
+}
+/* 0 = intel, 1 = amd-zen5, 2 = another table */
+int rno_rcp_profile_id(void) {
+  if (!memcmp(rcp_table, RN_RCP16_INTEL, sizeof rcp_host_table)) return 0;
+  if (!memcmp(rcp_table, RN_RCP16_AMD_ZEN5, sizeof rcp_host_table)) return 1;
+  return 2;
+}
 float rno_rcp(float x) {
   uint32_t b, r;
   float f;
   memcpy(&b, &x, 4);
-  r = RN_RCP_LUT_X86[(b >> 12) & 0x7ff] - ((b & 0x7f800000u) - 0x3f800000u);
+  r = rn_rcp_bits_from(rcp_table, b);
   memcpy(&f, &r, 4);
   return f;
 }

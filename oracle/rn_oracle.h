@@ -52,6 +52,8 @@ void rno_compute_rnn(const RnoModel *m, float *state, float *gains, float *vad, 
 void rno_band_energy(float *bandE, const float *X_ri);
 void rno_interp_band_gain(float *g481, const float *bandE);
 float rno_rcp(float x);
+int rno_set_rcp_profile(const char *name);  /* "intel" (default) | "amd-zen5" | "host"; 0 / -1 */
+int rno_rcp_profile_id(void);               /* 0 intel, 1 amd-zen5, 2 other */
 float rno_tanh(float x);
 float rno_sigmoid(float x);
 void rno_quantize_u8(unsigned char *q, const float *x, int n);

@@ -14,6 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RNNOISE_AMD_LIB", os.path.join(HERE, "librnnoise_amd.so"))  # env override: A/B builds
+# the instrumented build of the same sources (-DRN_INSTRUMENT=1): stage taps + probe kernels + include/rnnoise_amd_debug.h
+INSTR_LIB_PATH = os.path.join(HERE, "librnnoise_amd_instr.so")
 
 FRAME = 480
 NB_BANDS = 32
@@ -21,6 +23,8 @@ NB_FEATURES = 65
 STATE_FLOATS = 6282
 
 _lib = None
+_product = None
+_instr = None
 
 # every symbol declared in include/rnnoise.h and include/rnnoise_amd.h
 EXPORTS = [
@@ -31,8 +35,9 @@ EXPORTS = [
     "rnnoise_batch_reset", "rnnoise_batch_process", "rnnoise_batch_process_device",
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
-    "rnnoise_batch_kernel_ms", "rnnoise_batch_debug_pitch",
-    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_fft", "rnnoise_amd_model_pack", "rnnoise_batch_set_schedule",
+    "rnnoise_batch_kernel_ms",
+    "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_model_pack", "rnnoise_batch_set_schedule",
+    "rnnoise_amd_set_rcp_profile", "rnnoise_amd_rcp_profile",
 ]
 
 
@@ -50,15 +55,49 @@ def _share_hip_runtime_with_torch():
             C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
+# entry points of include/rnnoise_amd_debug.h: present in the instrumented library only
+DEBUG_EXPORTS = ["rnnoise_batch_debug_pitch", "rnnoise_amd_debug_fft", "rnnoise_amd_debug_log_energy"]
+
+
 def lib():
-    global _lib
+    """the library every call of this module goes to: the product, or -- inside `with instrumented():` -- its instrumented twin"""
+    global _lib, _product
     if _lib is None:
+        if _product is None:
+            _product = _load(LIB_PATH, debug=False)
+        _lib = _product
+    return _lib
+
+
+class instrumented:
+    """`with capi.instrumented():` -- models, batches and calls inside the block use librnnoise_amd_instr.so (taps compiled into
+    the kernels, probe kernels, the rnnoise_amd_debug.h entry points).  Objects must not cross the boundary: the two libraries
+    are separate images of the same code with separate state.  Tests and tools only; the product never loads it."""
+
+    def __enter__(self):
+        global _lib, _instr
+        self.prev = lib()
+        if _instr is None:
+            _instr = _load(INSTR_LIB_PATH, debug=True)
+        _lib = _instr
+        if self.prev is not _instr:
+            _instr.rnnoise_amd_set_rcp_profile(self.prev.rnnoise_amd_rcp_profile().split(b"=")[0])
+        return _instr
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def _load(path, debug):
+    if True:
         _share_hip_runtime_with_torch()
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
         L.rnnoise_get_size.restype = C.c_int
         L.rnnoise_get_frame_size.restype = C.c_int
@@ -90,15 +129,27 @@ def lib():
         L.rnnoise_model_weight_bytes.restype = C.c_long
         L.rnnoise_model_weight_bytes.argtypes = [vp]
         L.rnnoise_batch_debug_last.argtypes = [vp, fp, ip, ip]
-        L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
         L.rnnoise_batch_train_features.argtypes = [vp, fp, fp, fp, fp, ip, ip, ip, C.c_int]
         L.rnnoise_batch_train_features_device.argtypes = [vp] * 8 + [C.c_int, vp]
-        L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
-        L.rnnoise_amd_debug_fft.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), ip]
+        if debug:
+            L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
+            L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
+            L.rnnoise_amd_debug_fft.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), ip]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
-        _lib = L
-    return _lib
+        L.rnnoise_amd_set_rcp_profile.argtypes = [C.c_char_p]
+        L.rnnoise_amd_rcp_profile.restype = C.c_char_p
+    return L
+
+
+def set_rcp_profile(name: str) -> None:
+    """which CPU family's `rcpps` the activations reproduce: "host" (default) | "intel" | "amd-zen5" (include/rnnoise_amd.h)"""
+    if lib().rnnoise_amd_set_rcp_profile(name.encode()) != 0:
+        raise ValueError(f"unknown rcp profile {name!r}")
+
+
+def rcp_profile() -> str:
+    return lib().rnnoise_amd_rcp_profile().decode()
 
 
 def _fp(a):

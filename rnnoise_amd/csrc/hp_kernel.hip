@@ -163,7 +163,7 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
     o[2] = lpc[2] + c1 * lpc[1];
     o[3] = lpc[3] + c1 * lpc[2];
     o[4] = c1 * lpc[3];
-    if (g.debug) {
+    if (RN_INSTRUMENT && g.debug) {
 #pragma unroll
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
     }

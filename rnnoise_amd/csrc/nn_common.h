@@ -14,11 +14,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define KT 6           // 384 / 64 k-tiles of every int8 layer
 
 // ---- x86-profile activations (same arithmetic as nn_kernels.hip; LUT staged in LDS) ----
-__device__ __forceinline__ float rcp_x86(float x, const uint32_t *lut) {
-  uint32_t b = __float_as_uint(x);
-  return __uint_as_float(lut[(b >> 12) & 0x7ff] - ((b & 0x7f800000u) - 0x3f800000u));
-}
-__device__ __forceinline__ float tanh_x86(float x, const uint32_t *lut) {  // src/vec_avx.h:398-416
+__device__ __forceinline__ float rcp_x86(float x, const uint16_t *lut) { return rn_rcp_x86(x, lut); }
+__device__ __forceinline__ float tanh_x86(float x, const uint16_t *lut) {  // src/vec_avx.h:398-416
   const float N0 = 952.52801514f, N1 = 96.39235687f, N2 = 0.60863042f;
   const float D0 = 952.72399902f, D1 = 413.36801147f, D2 = 11.88600922f;
   float x2 = x * x;
@@ -29,7 +26,7 @@ __device__ __forceinline__ float tanh_x86(float x, const uint32_t *lut) {  // sr
   num = (1.f < num) ? 1.f : num;
   return (-1.f > num) ? -1.f : num;
 }
-__device__ __forceinline__ float sigmoid_x86(float x, const uint32_t *lut) {  // src/vec_avx.h:426-445
+__device__ __forceinline__ float sigmoid_x86(float x, const uint16_t *lut) {  // src/vec_avx.h:426-445
   const float N0 = 238.13200378f, N1 = 6.02452230f, N2 = 0.00950985f;
   const float D0 = 952.72399902f, D1 = 103.34200287f, D2 = 0.74287558f;
   float x2 = x * x;

@@ -10,13 +10,9 @@
 #define NN_THREADS 384
 
 // ---- x86-profile activations (src/vec_avx.h:398-445) with the captured rcpps table ----
-__device__ __forceinline__ float rcp_x86(float x, const uint32_t *__restrict__ lut) {
-  uint32_t b = __float_as_uint(x);
-  uint32_t r = lut[(b >> 12) & 0x7ff] - ((b & 0x7f800000u) - 0x3f800000u);
-  return __uint_as_float(r);
-}
+__device__ __forceinline__ float rcp_x86(float x, const uint16_t *__restrict__ lut) { return rn_rcp_x86(x, lut); }
 
-__device__ __forceinline__ float tanh_x86(float x, const uint32_t *__restrict__ lut) {
+__device__ __forceinline__ float tanh_x86(float x, const uint16_t *__restrict__ lut) {
   const float N0 = 952.52801514f, N1 = 96.39235687f, N2 = 0.60863042f;
   const float D0 = 952.72399902f, D1 = 413.36801147f, D2 = 11.88600922f;
   float x2 = x * x;
@@ -29,7 +25,7 @@ __device__ __forceinline__ float tanh_x86(float x, const uint32_t *__restrict__ 
   return (-1.f > num) ? -1.f : num;
 }
 
-__device__ __forceinline__ float sigmoid_x86(float x, const uint32_t *__restrict__ lut) {
+__device__ __forceinline__ float sigmoid_x86(float x, const uint16_t *__restrict__ lut) {
   const float N0 = 238.13200378f, N1 = 6.02452230f, N2 = 0.00950985f;
   const float D0 = 952.72399902f, D1 = 103.34200287f, D2 = 0.74287558f;
   float x2 = x * x;
@@ -89,7 +85,7 @@ extern "C" __global__ void __launch_bounds__(NN_THREADS)
 rn_nn_vector_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   __shared__ NnLds L;
   const int s = blockIdx.x, t = threadIdx.x;
-  const uint32_t *lut = tb.rcp_lut;
+  const uint16_t *lut = tb.rcp16;
   if (g.silence[s]) {  // src/denoise.c:474: the network and its state are untouched on silent frames
     if (t < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + t] = 0;
     if (t == 0) g.vad[s] = 0;

@@ -20,7 +20,7 @@
 #define GTHREADS (64 * GW)
 
 struct GruLds {
-  uint32_t lut[2048];            // rcpps table, pre-biased (rcp_b below)
+  uint16_t lut[4096];            // rcpps table (rn_dev.h: rcp16)
   int8_t xq[GM][KT * 64 * 16];   // layer input images
   int8_t hq[GM][KT * 64 * 16];   // recurrent state images
   float hrow[GW][24 / GW][GM * TS][16];  // per wave and unit tile: the f32 state of its 16 units for the workgroup's 64 streams
@@ -41,15 +41,11 @@ __device__ __forceinline__ void stg(void *base, unsigned byte_off, T v) {
 // ---- the activations and the quantiser of nn_common.h with fewer VALU operations (this kernel's main loop is VALU-bound) ----
 // Same bits for every finite argument -- which is all a GRU layer can see: its pre-activations are int32 sums times
 // finite scales plus diag * h, and h stays in [-1, 1] from a zero or any finite start.  What differs from nn_common.h:
-//   * the reciprocal's table arrives pre-biased (lut_b[i] = lut[i] + 0x3f800000), (a - (e - bias)) == ((a + bias) - e) mod 2^32;
 //   * the two clamps are one v_med3_f32 (differs from the x86 min/max pair only for a NaN argument);
 //   * the u8 quantiser is v_rndne + v_cvt_pk_u8_f32 (saturating both ways like packs/packus; differs only for
 //     |127 x + 127| >= 2^31, where cvtps2dq's "integer indefinite" turns a huge positive value into 0).
-__device__ __forceinline__ float rcp_b(float x, const uint32_t *lut_b) {
-  const uint32_t b = __float_as_uint(x);
-  return __uint_as_float(lut_b[(b >> 12) & 0x7ff] - (b & 0x7f800000u));
-}
-__device__ __forceinline__ float tanh_g(float x, const uint32_t *lut_b) {  // src/vec_avx.h:398-416
+__device__ __forceinline__ float rcp_b(float x, const uint16_t *lut) { return rn_rcp_x86(x, lut); }
+__device__ __forceinline__ float tanh_g(float x, const uint16_t *lut_b) {  // src/vec_avx.h:398-416
   const float N0 = 952.52801514f, N1 = 96.39235687f, N2 = 0.60863042f;
   const float D0 = 952.72399902f, D1 = 413.36801147f, D2 = 11.88600922f;
   const float x2 = x * x;
@@ -59,7 +55,7 @@ __device__ __forceinline__ float tanh_g(float x, const uint32_t *lut_b) {  // sr
   num = num * rcp_b(den, lut_b);
   return __builtin_amdgcn_fmed3f(num, -1.f, 1.f);
 }
-__device__ __forceinline__ float sigmoid_g(float x, const uint32_t *lut_b) {  // src/vec_avx.h:426-445
+__device__ __forceinline__ float sigmoid_g(float x, const uint16_t *lut_b) {  // src/vec_avx.h:426-445
   const float N0 = 238.13200378f, N1 = 6.02452230f, N2 = 0.00950985f;
   const float D0 = 952.72399902f, D1 = 103.34200287f, D2 = 0.74287558f;
   const float x2 = x * x;
@@ -134,14 +130,18 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
   GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
   const int N = g.n_streams, n_tiles = (N + TS - 1) / TS, tile0 = blockIdx.x * GM;
-  const uint32_t *lut = L.lut;
+  const uint16_t *lut = L.lut;
   float *st = g.gru_state + (size_t)layer * g.n_stride * RN_GRU;
   const int8_t *xin = g.act_q[layer];
   int8_t *himg = g.act_q[layer + 1];  // quantised state: read here, rewritten below (own tiles only)
 
   // (tests / profiling: shader-clock taps of wave 0, slots RN_DBG_CLK2 + 7 + 3 * layer + {0: prologue, 1: loads issued -> barrier, 2: tiles})
+#if RN_INSTRUMENT
   float *dbg = (g.debug && tid == 0) ? g.debug + (size_t)tile0 * TS * RN_DBG_FLOATS + RN_DBG_CLK2 + 7 + 3 * layer : nullptr;
-  const unsigned long long clk0 = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+#else
+  float *const dbg = nullptr;
+#endif
+  const unsigned long long clk0 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
   int sn[GM], sil[GM];
   bool live[GM];
 #pragma unroll
@@ -173,13 +173,13 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
       }
     }
     static_assert(GW >= 8, "the LUT is 8 pieces");
-    if (wave < 8) dma_1k(tb.rcp_lut_b + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
+    if (wave < 8) dma_1k(reinterpret_cast<const uint32_t *>(tb.rcp16) + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
     rows_fetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  const unsigned long long clk1 = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long clk1 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
   __builtin_amdgcn_s_barrier();
-  const unsigned long long clk2 = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long clk2 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
 
 #pragma unroll
   for (int t = 0; t < GM; t++) live[t] = (tile0 + t) * TS + n < N && !sil[t];  // silent streams keep their state (src/denoise.c:474)
@@ -412,12 +412,12 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_dense_kernel(RnGrou
     const v4f bs = *reinterpret_cast<const v4f *>(m.dense_out.bias + row0);
     v4f o;
 #pragma unroll
-    for (int r = 0; r < 4; r++) o[r] = live ? sigmoid_x86(dacc[r] + bs[r], tb.rcp_lut) : 0.f;
+    for (int r = 0; r < 4; r++) o[r] = live ? sigmoid_x86(dacc[r] + bs[r], tb.rcp16) : 0.f;
     if (s < N) *reinterpret_cast<v4f *>(g.gains + (size_t)sc * RN_NB_BANDS + row0) = o;
   }
   if (vad_wave) {
     const int vs = tile0 * TS + lane;
-    if (vs < N) g.vad[vs] = g.silence[vs] ? 0.f : sigmoid_x86(vacc + m.vad_dense.bias[0], tb.rcp_lut);
+    if (vs < N) g.vad[vs] = g.silence[vs] ? 0.f : sigmoid_x86(vacc + m.vad_dense.bias[0], tb.rcp16);
   }
 }
 

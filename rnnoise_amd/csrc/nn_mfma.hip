@@ -21,7 +21,7 @@
 #define CH_STRIDE 260  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
 
 struct MfmaLds {
-  uint32_t lut[2048];             // rcpps table
+  uint16_t lut[4096];             // rcpps table (rn_dev.h: rcp16)
   float vadw[RN_CAT];             // vad_dense weights: the lane = stream chain of wave 2 must not wait for L2 at every step
   union {
     struct {
@@ -47,7 +47,10 @@ __device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt,
 // MODE 0: the whole network for one tile.  Large batches run it layer by layer instead (nn_layers.hip): MODE 1 = the
 // front (conv1, conv2; leaves the quantised conv2 output as a B-fragment image in act_q[0]), then three launches of the
 // 64-stream GRU layer kernel, then the 64-stream dense kernel on the f32 activations the others left in HBM.
-extern "C" __global__ void __launch_bounds__(NTHREADS)  // (forcing <=128 VGPRs for 4 WGs/CU spills and is slower: measured)
+// Two workgroups per CU (4 waves per SIMD, <= 128 VGPRs) is what the 47 KB of LDS is sized for; left to itself the
+// allocator drifts between 121 and 162 VGPRs with unrelated edits, and above 128 only one workgroup fits.
+// "At least 4" costs 8 spilled registers, "exactly 4" 36.  (Forcing <= 64 VGPRs for 4 workgroups per CU is slower: measured.)
+extern "C" __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4)))
 rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 #define RN_NN_MODE 0
 #include "nn_tile_body.inc"

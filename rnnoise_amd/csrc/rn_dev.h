@@ -13,6 +13,11 @@
 //   the pitch ring (RN_RING_SLOTS = 6 slots of 480 samples = 2880 floats per stream).
 #pragma once
 #include <stdint.h>
+// 1: the instrumented build (librnnoise_amd_instr.so) -- stage taps and shader-clock probes compiled into the kernels, probe
+// kernels and the rnnoise_amd_debug.h entry points present.  0: the product library.
+#ifndef RN_INSTRUMENT
+#define RN_INSTRUMENT 0
+#endif
 #include "../../include/rn_layout.h"
 
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
@@ -34,8 +39,8 @@ struct RnTablesDev {
   const float *band_frac;     // [400]   (float)j/band_size of each bin (src/denoise.c:100)
   const uint16_t *bitrev;     // [960]   digit reversal of the 5.3.4.4.4 FFT (src/rnnoise_tables.c:10, by formula), padded position
   const uint8_t *band_of_bin; // [400]   band index i with eband[i] <= bin < eband[i+1]
-  const uint32_t *rcp_lut;    // [2048]  x86 rcpps stand-in (oracle/rcp_capture.c)
-  const uint32_t *rcp_lut_b;  // [2048]  rcp_lut[i] + 0x3f800000 (mod 2^32)
+  const uint16_t *rcp16;      // [4096]  x86 rcpps stand-in of the active host profile (rcp_profiles.h, oracle/rcp_capture.c):
+                              //         entry i = (bits(rcp(1 + i/4096)) - 0x3f000000) >> 11; see rn_rcp_bits()
   const float *fft_tw;        // [16][64][2] per-lane twiddles of the register-resident FFT (fft_reg.h: RN_FTW_*)
   const uint32_t *band_q;     // [400]  per bin: LDS slot of its (1-frac) term | slot of its frac term << 11 | band << 22
   const uint32_t *band_chain; // [34]   per band accumulator: first slot (16-byte aligned) | number of terms << 16
@@ -111,7 +116,15 @@ struct RnTrainArgs {
   float *rec;              // [N][98] out: features[65] | gain targets[32] | vad
 };
 
+// bits(rcpps(x)) for a positive normal x with bits b, from the 16-bit table entry v = rcp16[(b >> 11) & 0xfff]:
+//   (v << 11) + 0x3f000000 - ((b & 0x7f800000) - 0x3f800000)
+#define RN_RCP_K 0x7e800000u
 #ifdef __HIPCC__
+__device__ __forceinline__ float rn_rcp_x86(float x, const uint16_t *lut16) {
+  const uint32_t b = __float_as_uint(x);
+  const uint32_t v = lut16[(b >> 11) & 0xfff];
+  return __uint_as_float((v << 11) + (RN_RCP_K - (b & 0x7f800000u)));
+}
 #include <hip/hip_ext.h>
 // Launch with optional start / stop events: they are bound to the dispatch packet itself (hipExtLaunchKernel), so
 // timing a kernel or publishing its completion to another stream adds no packets to the queue.

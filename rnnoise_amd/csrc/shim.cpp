@@ -19,8 +19,11 @@
 #include <vector>
 
 #include "../../include/rnnoise_amd.h"
-#include "rcp_lut_x86.h"
 #include "rn_dev.h"
+#if RN_INSTRUMENT
+#include "../../include/rnnoise_amd_debug.h"
+#endif
+#include "rcp_profiles.h"
 
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t, hipEvent_t, hipEvent_t);
@@ -35,9 +38,11 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, 
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
+#if RN_INSTRUMENT
 extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);
+#endif
 extern "C" hipError_t rn_launch_state_gather(const RnGroupDev *, float *, int, int, hipStream_t);
 extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *, const float *, int, int, hipStream_t);
 
@@ -326,6 +331,64 @@ struct DeviceTables {
 std::mutex g_tables_mu;
 std::vector<DeviceTables> g_tables;
 
+// ---------------------------------------------------------------------------------------------
+// rcpps profile (rcp_profiles.h): which CPU family's approximate reciprocal the activations reproduce.
+// $RNNOISE_AMD_RCP_PROFILE = host (default; alias auto) | intel | amd-zen5 (alias amd), or rnnoise_amd_set_rcp_profile().
+// "host" captures the table from the CPU this process runs on; if that CPU's rcpps does not have the tabulated form
+// (never seen) the built-in table of the cpuid vendor is used and the fact goes to stderr.
+// ---------------------------------------------------------------------------------------------
+struct RcpProfile {
+  unsigned short t[RN_RCP_ENTRIES];
+  std::string name;
+  bool set = false;
+};
+RcpProfile g_rcp;  // guarded by g_tables_mu
+
+bool cpu_vendor_is_amd() {
+#if defined(__x86_64__) || defined(__i386__)
+  unsigned a = 0, b = 0, c = 0, d = 0;
+  __asm__ volatile("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(0), "c"(0));
+  return b == 0x68747541u && d == 0x69746e65u && c == 0x444d4163u;  // "AuthenticAMD"
+#else
+  return false;
+#endif
+}
+
+int rcp_select_locked(const char *want) {
+  std::string w = want ? want : "";
+  if (w.empty() || w == "auto") w = "host";
+  if (w == "amd") w = "amd-zen5";
+  if (w == "host") {
+    if (rn_rcp_capture_host(g_rcp.t) == 0) {
+      const bool is_intel = !memcmp(g_rcp.t, RN_RCP16_INTEL, sizeof g_rcp.t), is_amd = !memcmp(g_rcp.t, RN_RCP16_AMD_ZEN5, sizeof g_rcp.t);
+      g_rcp.name = is_intel ? "host=intel" : (is_amd ? "host=amd-zen5" : "host=captured");
+    } else {
+      const bool amd = cpu_vendor_is_amd();
+      fprintf(stderr, "[rnnoise_amd] this CPU's rcpps does not have the 12-bit table form; using the built-in '%s' profile\n",
+              amd ? "amd-zen5" : "intel");
+      memcpy(g_rcp.t, amd ? RN_RCP16_AMD_ZEN5 : RN_RCP16_INTEL, sizeof g_rcp.t);
+      g_rcp.name = amd ? "amd-zen5" : "intel";
+    }
+  } else if (w == "intel") {
+    memcpy(g_rcp.t, RN_RCP16_INTEL, sizeof g_rcp.t);
+    g_rcp.name = "intel";
+  } else if (w == "amd-zen5") {
+    memcpy(g_rcp.t, RN_RCP16_AMD_ZEN5, sizeof g_rcp.t);
+    g_rcp.name = "amd-zen5";
+  } else {
+    fprintf(stderr, "[rnnoise_amd] unknown rcp profile '%s' (host | intel | amd-zen5)\n", w.c_str());
+    return -1;
+  }
+  g_rcp.set = true;
+  return 0;
+}
+
+int rcp_ensure_locked() {
+  if (g_rcp.set) return 0;
+  if (rcp_select_locked(getenv("RNNOISE_AMD_RCP_PROFILE")) == 0) return 0;
+  return rcp_select_locked("host");
+}
+
 int tables_for_device(int device, RnTablesDev &out) {
   std::lock_guard<std::mutex> lk(g_tables_mu);
   for (auto &t : g_tables)
@@ -415,16 +478,13 @@ int tables_for_device(int device, RnTablesDev &out) {
       for (int bin = kEband[b]; bin < kEband[b + 1]; bin++)
         band_q[bin] = (uint32_t)(start[b] + bin - lo[b]) | ((uint32_t)(start[b + 1] + bin - lo[b + 1]) << 11) | ((uint32_t)b << 22);
   }
-  // the same table with the exponent bias of the reciprocal folded in (nn_layers.hip: one integer subtract less per activation)
-  std::vector<uint32_t> lut_b(2048);
-  for (int i = 0; i < 2048; i++) lut_b[i] = RN_RCP_LUT_X86[i] + 0x3f800000u;
+  if (rcp_ensure_locked()) return -1;
   Staging st;
-  size_t o_lb = st.add(lut_b.data(), 4 * lut_b.size());
   size_t o_ftw = st.add(ftw.data(), 4 * ftw.size());
   size_t o_bq = st.add(band_q.data(), 4 * band_q.size()), o_bc = st.add(band_chain.data(), 4 * band_chain.size());
   size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
          o_t = st.add(tw.data(), 4 * tw.size()), o_f = st.add(frac.data(), 4 * frac.size()),
-         o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(RN_RCP_LUT_X86, sizeof RN_RCP_LUT_X86),
+         o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(g_rcp.t, sizeof g_rcp.t),
          o_br = st.add(bitrev.data(), 2 * bitrev.size());
   DeviceTables t;
   t.device = device;
@@ -438,8 +498,7 @@ int tables_for_device(int device, RnTablesDev &out) {
   t.dev.band_frac = reinterpret_cast<const float *>(base + o_f);
   t.dev.band_of_bin = base + o_b;
   t.dev.bitrev = reinterpret_cast<const uint16_t *>(base + o_br);
-  t.dev.rcp_lut = reinterpret_cast<const uint32_t *>(base + o_r);
-  t.dev.rcp_lut_b = reinterpret_cast<const uint32_t *>(base + o_lb);
+  t.dev.rcp16 = reinterpret_cast<const uint16_t *>(base + o_r);
   t.dev.fft_tw = reinterpret_cast<const float *>(base + o_ftw);
   t.dev.band_q = reinterpret_cast<const uint32_t *>(base + o_bq);
   t.dev.band_chain = reinterpret_cast<const uint32_t *>(base + o_bc);
@@ -618,7 +677,15 @@ bool unpack_model(const void *p, int len, StagedModel &sm, long &weight_bytes) {
                                   {RN_CAT, RN_NB_BANDS}, {RN_CAT, 1}};
   for (int i = 0; i < 10; i++) {
     const PackLayer &l = h.layers[i];
+    // What kind of layer sits at position i is the architecture's business, not the file's: conv1 / dense_out / vad_dense
+    // float, conv2 dense int8, gru input matrices block-sparse int8, recurrent ones block-sparse int8 + diagonal
+    // (linear_from_blob's `kind`).  A pack whose flags say otherwise would make the kernels dereference null weight /
+    // scale / diagonal pointers or take the dense branch over a sparse weight array.
+    const bool k_int8 = i >= 1 && i <= 7, k_diag = i == 3 || i == 5 || i == 7, k_cols = i >= 2 && i <= 7;
+    if ((l.is_int8 != 0) != k_int8 || (l.has_fw != 0) != !k_int8 || (l.has_diag != 0) != k_diag || (l.has_cols != 0) != k_cols)
+      return false;
     if (l.nin != want[i][0] || l.nout != want[i][1] || l.nblocks < 0 || l.nblocks > (l.nin / 4) * (l.nout / 8)) return false;
+    if (k_int8 && !k_cols && l.nblocks != (l.nin / 4) * (l.nout / 8)) return false;  // a dense int8 layer has every block
     auto fits = [&](uint64_t off, uint64_t bytes) { return off <= n && bytes <= n - off && !(off & 15); };
     const uint64_t no = l.nout, ni = l.nin;
     if (!fits(l.bias, 4 * no)) return false;
@@ -635,13 +702,14 @@ bool unpack_model(const void *p, int len, StagedModel &sm, long &weight_bytes) {
         if (grp[gidx + 1] < grp[gidx]) return false;
       for (int b = 0; b < l.nblocks; b++)
         if (cols[b] + 3 >= l.nin || (cols[b] & 3)) return false;
-    } else if (!l.has_fw || !fits(l.fw, 4 * no * ni) || (no % 16 == 0 && !fits(l.wmf, 4 * no * ((ni + 15) / 16) * 16))) {
+    } else if (!fits(l.fw, 4 * no * ni) || (no % 16 == 0 && (!l.wmf || !fits(l.wmf, 4 * no * ((ni + 15) / 16) * 16)))) {
       return false;
     }
     DevLinearOffsets &o = sm.off[i];
     o.bias = l.bias; o.fw = l.fw; o.scale = l.scale; o.diag = l.diag; o.w = l.w; o.wmf = l.wmf; o.rowsum = l.rowsum;
     o.grp = l.grp; o.cols = l.cols;
-    o.has_fw = l.has_fw; o.has_diag = l.has_diag; o.has_cols = l.has_cols; o.is_int8 = l.is_int8;
+    o.has_fw = !k_int8; o.has_diag = k_diag; o.has_cols = k_cols; o.is_int8 = k_int8;
+    if (!k_int8 && no % 16 != 0) o.wmf = 0;  // (vad_dense: no MFMA-ordered copy; whatever the file says there is not used)
     sm.lin[i] = HostLinear();
     sm.lin[i].nin = l.nin;
     sm.lin[i].nout = l.nout;
@@ -826,6 +894,31 @@ struct TimedLaunch {
 // =============================================================================================
 // batched API
 // =============================================================================================
+// Select the rcpps profile (rcp_profiles.h) for every model and batch of this process, now and later: the table is
+// re-uploaded to each device that already holds one (after draining it).  name: "host" | "intel" | "amd-zen5".
+extern "C" int rnnoise_amd_set_rcp_profile(const char *name) {
+  std::lock_guard<std::mutex> lk(g_tables_mu);
+  RcpProfile keep = g_rcp;
+  if (rcp_select_locked(name && *name ? name : "host")) {
+    g_rcp = keep;
+    return -1;
+  }
+  for (auto &t : g_tables) {
+    ON_DEVICE(t.device);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(const_cast<uint16_t *>(t.dev.rcp16), g_rcp.t, sizeof g_rcp.t, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// Name of the active profile: "intel", "amd-zen5", or "host=intel" / "host=amd-zen5" / "host=captured" when the table was
+// taken from this CPU (and which built-in table, if any, it equals).  The pointer stays valid until the next set call.
+extern "C" const char *rnnoise_amd_rcp_profile(void) {
+  std::lock_guard<std::mutex> lk(g_tables_mu);
+  if (rcp_ensure_locked()) return "";
+  return g_rcp.name.c_str();
+}
+
 extern "C" int rnnoise_amd_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1308,6 +1401,7 @@ extern "C" int rnnoise_batch_debug_last(RNNoiseBatch *b, float *features, int *s
   return 0;
 }
 
+#if RN_INSTRUMENT  // ---- test / measurement taps: instrumented build only (include/rnnoise_amd_debug.h) ----
 // pitch stage taps of the last step ([N][RN_DBG_FLOATS]); the first call (dst==NULL) arms them
 extern "C" int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst) {
   if (!b) return -1;
@@ -1365,6 +1459,8 @@ extern "C" int rnnoise_amd_debug_log_energy(int device, float *out, const float 
   hipFree(d);
   return rc;
 }
+
+#endif  // RN_INSTRUMENT
 
 extern "C" int rnnoise_batch_enable_timing(RNNoiseBatch *b, int on) {
   if (!b) return -1;
@@ -1683,10 +1779,33 @@ extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float
   StatePool *pool = nullptr;
   int slot = -1;
   if (pool_acquire(m, pool, slot)) return frame_failed(out, "no GPU state row available (no CPU fallback)");
-  struct Scratch {  // per-thread: a stream and a pinned staging block, created on first use
+  struct Scratch {  // per-thread: a stream and a pinned staging block, created on first use, released at thread exit
     hipStream_t stream = nullptr;
     float *h = nullptr;
     int device = -1;
+    bool ready(int dev) {  // both resources or neither: a half-built scratch is torn down and retried at the next call
+      if (stream && h && device == dev) return true;
+      release();
+      if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
+      if (hipHostMalloc((void **)&h, 2 * StatePool::FLAT_BLK * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        h = nullptr;
+        release();
+        return false;
+      }
+      device = dev;
+      return true;
+    }
+    void release() {
+      if (stream || h) {
+        DeviceGuard guard(device >= 0 ? device : 0);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (h) (void)hipHostFree(h);
+      }
+      stream = nullptr;
+      h = nullptr;
+      device = -1;
+    }
+    ~Scratch() { release(); }
   };
   static thread_local Scratch sc;
   float vad = 0.f;
@@ -1694,8 +1813,7 @@ extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float
   {
     DeviceGuard guard(pool->batch->device);
     constexpr size_t IO = StatePool::FLAT_IO, UP = IO + RN_FRAME_SIZE, DOWN = UP + 1;
-    if (guard.ok && (sc.stream || (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) == hipSuccess &&
-                                   hipHostMalloc((void **)&sc.h, 2 * StatePool::FLAT_BLK * sizeof(float), hipHostMallocDefault) == hipSuccess))) {
+    if (guard.ok && sc.ready(pool->batch->device)) {
       float *d_blk = pool->d_flat + (size_t)slot * StatePool::FLAT_BLK, *d_io = d_blk + IO;  // frame processed in place
       const RnGroupDev v = group_view(pool->batch->g, slot, 1);
       // conventions of a freshly scattered row: its newest frame sits in ring slot 5 and spectra slot 2, so the next frame

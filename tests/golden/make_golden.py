@@ -15,6 +15,11 @@ running it.
   tests/golden/edge_default.npz  -- loud noise / DC / impulses / gaps, 60 frames each
   tests/golden/digest_little.npz -- 2 streams x 200 frames on the sparser model
 
+The reference's tanh / sigmoid execute the generating CPU's `rcpps` (src/vec_avx.h:413,442), so a fixture belongs to one
+CPU family and says which ("rcp_profile", "host_cpu" entries).  The Intel build host writes tests/golden/*.npz; run on the
+GPU boxes' AMD EPYC host (the compiled reference under oracle/_ref travels there) the same script writes the same streams
+into tests/golden/amd_zen5/ -- `python tests/golden/make_golden.py [OUTDIR]`.
+
 Usage:  make -C oracle ref && python tests/golden/make_golden.py
 """
 import lzma
@@ -26,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+from oracle import binding  # noqa: E402
 from oracle.binding import RefHarness  # noqa: E402
 from rnnoise_amd import synth  # noqa: E402
 
@@ -49,10 +55,31 @@ def edge_inputs():
     return dict(loud=loud, dc=dc, impulses=imp, gaps=gaps)
 
 
+def host_profile():
+    """The reference executes this CPU's rcpps (src/vec_avx.h:413,442): its outputs belong to one CPU family, and every
+    fixture says which (rnnoise_amd/csrc/rcp_profiles.h).  A host whose table is neither built-in one cannot make goldens."""
+    binding.set_rcp_profile("host")
+    name = binding.rcp_profile()
+    assert name in ("intel", "amd-zen5"), "this CPU's rcpps matches no committed profile: capture it first (oracle/rcp_capture.c)"
+    cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+    return dict(rcp_profile=np.array(name), host_cpu=np.array(cpu))
+
+
 def main():
+    global GOLD
+    tag = host_profile()
+    blob_dir = GOLD
+    if str(tag["rcp_profile"]) != "intel":
+        GOLD = os.path.join(GOLD, str(tag["rcp_profile"]).replace("-", "_"))
+    if len(sys.argv) > 1:
+        GOLD = sys.argv[1]
+    os.makedirs(GOLD, exist_ok=True)
     for name in ("default", "little"):
         blob = open(os.path.join(ROOT, "oracle", "_ref", f"{name}.blob"), "rb").read()
-        with open(os.path.join(GOLD, f"{name}.blob.xz"), "wb") as f:
+        path = os.path.join(blob_dir, f"{name}.blob.xz")
+        if os.path.exists(path) and lzma.decompress(open(path, "rb").read()) == blob:
+            continue  # unchanged: keep the committed bytes
+        with open(path, "wb") as f:
             f.write(lzma.compress(blob, preset=9))
     blob = open(os.path.join(ROOT, "oracle", "_ref", "default.blob"), "rb").read()
 
@@ -67,7 +94,7 @@ def main():
         for k, v in res.items():
             d[f"s{s}_{k}"] = v
         d[f"s{s}_state"] = r.get_state()
-    np.savez_compressed(os.path.join(GOLD, "detail_default.npz"), **d)
+    np.savez_compressed(os.path.join(GOLD, "detail_default.npz"), **d, **tag)
 
     # ---- digest ----
     d = {}
@@ -82,7 +109,7 @@ def main():
         d[f"s{s}_gains"] = res["gains"]
         d[f"s{s}_out_crc"] = crc_rows(res["out"])
         d[f"s{s}_state_crc"] = np.uint32(synth.crc32(r.get_state()))
-    np.savez_compressed(os.path.join(GOLD, "digest_default.npz"), **d)
+    np.savez_compressed(os.path.join(GOLD, "digest_default.npz"), **d, **tag)
 
     # ---- edge cases ----
     d = {}
@@ -96,7 +123,7 @@ def main():
         d[f"{name}_silence"] = res["silence"].astype(np.int8)
         d[f"{name}_out_crc"] = crc_rows(res["out"])
         d[f"{name}_state_crc"] = np.uint32(synth.crc32(r.get_state()))
-    np.savez_compressed(os.path.join(GOLD, "edge_default.npz"), **d)
+    np.savez_compressed(os.path.join(GOLD, "edge_default.npz"), **d, **tag)
 
     # ---- sparser model ----
     blob2 = open(os.path.join(ROOT, "oracle", "_ref", "little.blob"), "rb").read()
@@ -112,7 +139,7 @@ def main():
         d[f"s{s}_gains"] = res["gains"]
         d[f"s{s}_out_crc"] = crc_rows(res["out"])
         d[f"s{s}_state_crc"] = np.uint32(synth.crc32(r.get_state()))
-    np.savez_compressed(os.path.join(GOLD, "digest_little.npz"), **d)
+    np.savez_compressed(os.path.join(GOLD, "digest_little.npz"), **d, **tag)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

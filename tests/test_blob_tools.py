@@ -122,3 +122,13 @@ def test_corrupt_packs_are_rejected(blob_default):
     bad = bytearray(good); struct.pack_into("<i", bad, lay + 9 * 8 + 16 + 8, 10 ** 6); assert rejected(bad)          # absurd block count
     cols = h["header_bytes"] + h["layers"][2]["offsets"]["cols"]
     bad = bytearray(good); struct.pack_into("<H", bad, cols, 382); assert rejected(bad)                 # column index past the input
+    # the four kind flags (u32 has_fw, has_diag, has_cols, is_int8 after the nine offsets) are the architecture's, not the
+    # file's: flipping any of them on any layer is a rejection, not a null pointer or an out-of-bounds read on the device
+    for layer in range(10):
+        for flag in range(4):
+            off = 56 + layer * 104 + 9 * 8 + 4 * flag
+            bad = bytearray(good)
+            struct.pack_into("<I", bad, off, 0 if struct.unpack_from("<I", good, off)[0] else 1)
+            assert rejected(bad), (layer, flag)
+    lay1 = 56 + 1 * 104                                                                                 # conv2: dense int8
+    bad = bytearray(good); struct.pack_into("<i", bad, lay1 + 9 * 8 + 16 + 8, 7); assert rejected(bad)  # a dense layer with 7 blocks

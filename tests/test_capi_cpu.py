@@ -39,6 +39,24 @@ def test_library_exports_every_declared_symbol():
         assert re.search(rf"\bT {n}\b", nm), f"{n} not a defined text symbol"
 
 
+def test_product_library_exports_the_api_and_nothing_else():
+    """librnnoise_amd.so and librnnoise.so.0: every dynamic symbol is one declared in include/rnnoise.h / rnnoise_amd.h -- no
+    launch helpers, kernel stubs, probe kernels or debug taps (those live in the instrumented library, whose extra entry
+    points are the ones of include/rnnoise_amd_debug.h)"""
+    decl = set(declared_symbols())
+    for so in (capi.LIB_PATH, os.path.join(ROOT, "rnnoise_amd", "librnnoise.so.0")):
+        nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+        syms = {l.split()[-1] for l in nm.splitlines() if l.strip()}
+        assert syms == decl, (so, sorted(syms ^ decl))
+    dbg = re.findall(r"RNNOISE_EXPORT\s+[\w\s\*]+?\b(rnnoise_\w+)\s*\(", open(os.path.join(ROOT, "include", "rnnoise_amd_debug.h")).read())
+    assert sorted(dbg) == sorted(capi.DEBUG_EXPORTS)
+    nm = subprocess.run(["nm", "-D", "--defined-only", capi.INSTR_LIB_PATH], capture_output=True, text=True).stdout
+    for n in list(decl) + dbg:
+        assert re.search(rf"\bT {n}\b", nm), f"{n} missing from the instrumented library"
+    # no tap code in the product kernels: the instrumented image is the bigger one
+    assert os.path.getsize(capi.INSTR_LIB_PATH) > os.path.getsize(capi.LIB_PATH)
+
+
 def test_frame_geometry_and_state_size():
     L = capi.lib()
     assert L.rnnoise_get_frame_size() == 480  # rnnoise.h:62
@@ -129,3 +147,23 @@ def test_product_never_touches_the_oracle():
                     assert bad not in code, f"{f} references {bad}"
     ldd = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in ldd and "rnnoise_ref" not in ldd
+
+
+def test_rcp_profile_selection_is_host_side_and_named():
+    """include/rnnoise_amd.h: the profile is process-wide host state (no GPU needed to pick it); "host" captures this CPU's
+    rcpps and says which built-in table, if any, it equals"""
+    capi.set_rcp_profile("intel")
+    assert capi.rcp_profile() == "intel"
+    capi.set_rcp_profile("amd")
+    assert capi.rcp_profile() == "amd-zen5"
+    capi.set_rcp_profile("host")
+    name = capi.rcp_profile()
+    assert name in ("host=intel", "host=amd-zen5", "host=captured")
+    cpu = open("/proc/cpuinfo").read()
+    if "GenuineIntel" in cpu:
+        assert name == "host=intel"
+    if "AMD EPYC 9" in cpu and "9575F" in cpu:
+        assert name == "host=amd-zen5"
+    with pytest.raises(ValueError):
+        capi.set_rcp_profile("m68k")
+    assert capi.rcp_profile() == name  # a rejected name changes nothing

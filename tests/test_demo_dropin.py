@@ -36,6 +36,7 @@ def test_reference_demo_compiles_and_links_against_our_header_and_library():
 
 
 @pytest.mark.gpu
+@pytest.mark.rcp("host")  # what a deployed process gets by default: the rcpps of the CPU it runs on, in the demo and in the oracle
 def test_demo_output_is_byte_identical(tmp_path):
     if not os.path.exists(DEMO_BIN):
         pytest.skip("tests/_build/rnnoise_demo_dropin not built (needs the reference sources at build time)")
@@ -71,6 +72,7 @@ def test_our_library_carries_the_reference_soname():
 
 
 @pytest.mark.gpu
+@pytest.mark.rcp("host")
 def test_already_linked_reference_demo_runs_on_our_library(tmp_path):
     """The reference's demo, built and linked against the REFERENCE's librnnoise.so.0 (no rpath, NULL model = compiled-in
     weights), run twice: on the reference library, and with LD_LIBRARY_PATH pointing at ours plus the default-model blob.
@@ -94,16 +96,15 @@ def test_already_linked_reference_demo_runs_on_our_library(tmp_path):
     dt = time.perf_counter() - t0
     ref = (tmp_path / "ref.raw").read_bytes()
     ours = (tmp_path / "ours.raw").read_bytes()
-    # The parity contract is pinned to the x86 profile of the host that produced the goldens (its `rcpps` table, SURVEY
-    # fact 6): the oracle carries that table, the reference library running on THIS box's CPU may not (Intel build host vs
-    # AMD EPYC GPU box).  So: ours == oracle always; ours == the reference run here whenever that run equals the oracle.
+    # The reference's tanh / sigmoid execute THIS CPU's rcpps (src/vec_avx.h:413,442): its output is a function of the host.
+    # Our library's default profile captures the same instruction at load time (rcp_profiles.h), the oracle is told to do the
+    # same ("host"): all three must agree on whatever box this runs on -- Intel build host or AMD EPYC GPU box.
+    from oracle import binding
     from oracle.binding import Oracle
     pcm = np.fromfile(tmp_path / "in.raw", dtype=np.int16)
     want = Oracle(blob).run(pcm.astype(np.float32).reshape(T, 480))["out"][1:].astype(np.int16).tobytes()
     assert len(ref) == (T - 1) * 480 * 2 and len(ours) == len(ref)
+    assert ours == ref, "already-linked reference demo: our library's bytes differ from the reference library's on this host"
     assert ours == want, "already-linked reference demo on our library: bytes differ from the oracle"
-    same_host_profile = ref == want
-    if same_host_profile:
-        assert ours == ref
     print(f"configs[0]: {T} frames through the pooled drop-in path in {dt:.2f} s wall ({T / dt:.0f} frames/s incl. process "
-          f"start); reference library on this host {'matches' if same_host_profile else 'differs from (different rcpps)'} the pinned profile")
+          f"start); ours == reference library == oracle on this host (rcp profile of the oracle: {binding.rcp_profile()})")

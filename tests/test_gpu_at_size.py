@@ -19,26 +19,41 @@ from test_gpu_parity import oracle_run
 pytestmark = pytest.mark.gpu
 
 
-def _tiled_check(blob, N, T, silent_stream):
+def _tiled_check(blob, N, calls, silent_stream):
+    """N streams = N/32 replicas of a 32-stream block, fed from HBM through rnnoise_batch_process_device in `calls` (frames per
+    call) on the batch's DEFAULT schedule -- what bench.py times: multi-frame calls run the three-stream frame pipeline
+    (high-pass two frames ahead, analysis(f+1) beside network + synthesis(f)), the 6-slot pitch ring and the 3 spectra slots
+    wrap, call boundaries fall inside the ring, the network runs layer-wise from 16,384 streams up and the analysis kernel
+    four streams per workgroup.  A one-frame call in the middle takes the unpipelined route through the same state."""
+    import torch
+    T = sum(calls)
     base = synth.batch_pcm(range(32), T)
     base[:3, silent_stream] = 0                       # silent for 3 frames, then live
-    pcm = np.ascontiguousarray(np.tile(base, (1, N // 32, 1)))
+    base[T - 5:T - 3, (silent_stream + 3) % 32] = 0   # another one goes silent across the last call boundary region
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(base).to(dev).repeat(1, N // 32, 1).contiguous()
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty((T, N), device=dev)
+    d_gains = torch.empty((T, N, 32), device=dev)
     m = capi.Model(blob)
     b = capi.Batch(m, N)
     assert b.set_nn_path(1) == 1                      # MFMA path is the default at this size
-    out, vad, gains = b.process(pcm)
-    del pcm
-    o4 = out.reshape(T, N // 32, 32, 480).view(np.uint32)
-    assert (o4 == o4[:, :1]).all(), "replicated streams diverged (pcm)"
-    g4 = gains.reshape(T, N // 32, 32, 32).view(np.uint32)
-    assert (g4 == g4[:, :1]).all(), "replicated streams diverged (gains)"
-    v4 = vad.reshape(T, N // 32, 32).view(np.uint32)
-    assert (v4 == v4[:, :1]).all(), "replicated streams diverged (vad)"
+    st = torch.cuda.current_stream().cuda_stream
+    f = 0
+    for n in calls:
+        b.process_device(d_out[f].data_ptr(), d_in[f].data_ptr(), d_vad[f].data_ptr(), d_gains[f].data_ptr(), n, st)
+        f += n
+    torch.cuda.synchronize()
+    for name, t, w in (("pcm", d_out, 480), ("gains", d_gains, 32), ("vad", d_vad, 1)):
+        r = t.view(torch.int32).reshape(T, N // 32, 32 * w)
+        assert bool((r == r[:, :1]).all().item()), f"replicated streams diverged ({name})"
+    out, gains, vad = d_out[:, :32].cpu().numpy(), d_gains[:, :32].cpu().numpy(), d_vad[:, :32].cpu().numpy()
+    del d_in, d_out, d_gains, d_vad
     want = oracle_run(blob, base)
     assert want["silence"][:, silent_stream].any() and not want["silence"][:, 0].any()
-    assert_bits_equal(out[:, :32], want["out"], "pcm")
-    assert_bits_equal(gains[:, :32], want["gains"], "gains")
-    assert_bits_equal(vad[:, :32], want["vad"], "vad")
+    assert_bits_equal(out, want["out"], "pcm")
+    assert_bits_equal(gains, want["gains"], "gains")
+    assert_bits_equal(vad, want["vad"], "vad")
     for s_ in (0, 15, 16, silent_stream, 31):
         assert_bits_equal(b.export_state(N - 32 + s_), want["state"][s_], f"state of stream {N - 32 + s_}")
     # a stream from the middle of the batch as well (different XCD / tile than the first and the last block)
@@ -49,13 +64,46 @@ def _tiled_check(blob, N, T, silent_stream):
 
 
 def test_65536_stream_batch_properties(blob_default):
-    """BASELINE configs[2] = the bench default"""
-    _tiled_check(blob_default, 65536, 6, silent_stream=21)
+    """BASELINE configs[2] = the bench default: 14 frames as calls of 5 + 1 + 8"""
+    _tiled_check(blob_default, 65536, (5, 1, 8), silent_stream=21)
 
 
 def test_sparser_model_32768(blob_little):
-    """BASELINE configs[3]: the sparser blob at 32,768 streams"""
-    _tiled_check(blob_little, 32768, 6, silent_stream=9)
+    """BASELINE configs[3]: the sparser blob at 32,768 streams, 14 frames as calls of 5 + 1 + 8"""
+    _tiled_check(blob_little, 32768, (5, 1, 8), silent_stream=9)
+
+
+@pytest.mark.rcp("host")
+def test_16384_streams_on_the_host_profile(blob_default):
+    """the smallest batch on the layer-wise network, on the profile a deployed process gets by default (this CPU's rcpps)"""
+    _tiled_check(blob_default, 16384, (3, 4), silent_stream=5)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_register_fft_bit_exact(variant):
+    """F1 in isolation: the register-resident 960-point transform of the analysis / synthesis kernels (fft_reg.h; reference
+    rnn_fft_c, src/kiss_fft.c:518-586) against the oracle's FFT on random, impulse, DC, alternating, tiny (denormal products)
+    and huge inputs.  variant 0 = every exchange through ds_bpermute, 1 = the DPP / swizzle forms the kernels use."""
+    import ctypes as C
+    rng = np.random.default_rng(960 + variant)
+    cases = [(rng.standard_normal((960, 2)) * 3000).astype(np.float32) for _ in range(6)]
+    imp = np.zeros((960, 2), np.float32); imp[0, 0] = 1; cases.append(imp)
+    imp2 = np.zeros((960, 2), np.float32); imp2[517, 1] = -32768; cases.append(imp2)
+    cases.append(np.full((960, 2), 12345.678, np.float32))                                   # DC
+    alt = np.zeros((960, 2), np.float32); alt[::2, 0] = 1; alt[1::2, 0] = -1; cases.append(alt)  # Nyquist
+    cases.append((rng.standard_normal((960, 2)) * 1e-38).astype(np.float32))                 # denormal inputs and products
+    cases.append((rng.standard_normal((960, 2)) * 1e30).astype(np.float32))                  # no overflow at 1e30 / 960 * 960
+    real = (rng.standard_normal((960, 2)) * 8000).astype(np.float32); real[:, 1] = 0; cases.append(real)  # what the kernels feed it
+    cases.append(np.zeros((960, 2), np.float32))
+    x = np.ascontiguousarray(np.stack(cases))
+    y = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    with capi.instrumented() as L:  # the probe kernels live in the instrumented library (include/rnnoise_amd_debug.h)
+        rc = L.rnnoise_amd_debug_fft(0, variant, y.ctypes.data_as(fp), x.ctypes.data_as(fp), len(cases), 1, None, None)
+    assert rc == 0
+    for i, c in enumerate(cases):
+        want = Oracle.fft(c.reshape(-1)).reshape(960, 2)
+        assert_bits_equal(y[i], want, f"fft case {i} variant {variant}")
 
 
 def test_log10_device_vs_host_sweep():
@@ -70,7 +118,8 @@ def test_log10_device_vs_host_sweep():
         np.array([0.0, 1e-30, 0.99, 1.0, 9.99, 1e15], np.float32),
     ])
     got = np.empty_like(ex)
-    assert capi.lib().rnnoise_amd_debug_log_energy(0, capi._fp(got), capi._fp(ex), ex.size) == 0
+    with capi.instrumented() as L:
+        assert L.rnnoise_amd_debug_log_energy(0, capi._fp(got), capi._fp(ex), ex.size) == 0
     want = Oracle.log_energy(ex)
     ne = got.view(np.uint32) != want.view(np.uint32)
     n_diff = int(ne.sum())

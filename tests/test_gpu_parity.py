@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal, golden
+from conftest import both_profiles, assert_bits_equal, golden
 from oracle.binding import Oracle
 from rnnoise_amd import capi, synth
 
@@ -69,9 +69,32 @@ SECTIONS = [("xlp", 0, 864), ("ac", 864, 869), ("lpc2", 869, 874), ("xcorr_coars
             ("xcorr_fine", 1040, 1334), ("doubling", 1340, 1347)]
 
 
-def test_pitch_stage_taps(model, blob_default):
+def test_pitch_stage_taps(blob_default):
     """teacher-forced pitch analysis: every intermediate of rnn_pitch_downsample / rnn_pitch_search /
-    rnn_remove_doubling against the oracle, fed with the GPU's own pitch buffer"""
+    rnn_remove_doubling against the oracle, fed with the GPU's own pitch buffer.  The taps exist in the instrumented build
+    of the kernels only (librnnoise_amd_instr.so, include/rnnoise_amd_debug.h): same sources, -DRN_INSTRUMENT=1."""
+    with capi.instrumented():
+        _pitch_stage_taps(capi.Model(blob_default), blob_default)
+
+
+@pytest.mark.parametrize("n", [3, 70])
+def test_instrumented_build_computes_the_same_bits(blob_default, n):
+    """the instrumented library is the same code with taps: same outputs as the product library (70 streams: MFMA tiles)"""
+    T = 12
+    pcm = synth.batch_pcm([(7 * s) % 9 for s in range(n)], T, lead_silence=1)
+    a = capi.Batch(capi.Model(blob_default), n).process(pcm)
+    with capi.instrumented():
+        m = capi.Model(blob_default)
+        b = capi.Batch(m, n)
+        b.debug_pitch(arm_only=True)
+        c = b.process(pcm)
+        b.close()
+        m.close()
+    for x, y, name in zip(a, c, ("pcm", "vad", "gains")):
+        assert_bits_equal(x, y, name)
+
+
+def _pitch_stage_taps(model, blob_default):
     streams = [3, 8]
     T = 14
     pcm = synth.batch_pcm(streams, T, lead_silence=2)
@@ -113,6 +136,7 @@ def test_free_running_bit_exact_with_stage_taps(model, blob_default):
     assert want["silence"][:6].all() and not want["silence"][8:].any()
 
 
+@both_profiles
 def test_detail_golden_from_reference(model):
     """reference outputs recorded in the build container (tests/golden/make_golden.py)"""
     g = golden("detail_default.npz")
@@ -129,6 +153,7 @@ def test_detail_golden_from_reference(model):
         assert_bits_equal(b.export_state(i), g[f"s{s}_state"], "state")
 
 
+@both_profiles
 def test_digest_golden_400_frames(model):
     g = golden("digest_default.npz")
     streams = (0, 1, 159, 4095)
@@ -147,6 +172,7 @@ def test_digest_golden_400_frames(model):
         assert synth.crc32(b.export_state(i)) == int(g[f"s{s}_state_crc"])
 
 
+@both_profiles
 def test_edge_case_golden(model):
     g = golden("edge_default.npz")
     names = ["loud", "dc", "impulses", "gaps"]
@@ -160,6 +186,7 @@ def test_edge_case_golden(model):
         assert synth.crc32(b.export_state(i)) == int(g[f"{n}_state_crc"]), n
 
 
+@both_profiles
 def test_sparser_model_golden(blob_little):
     g = golden("digest_little.npz")
     m = capi.Model(blob_little)
@@ -479,6 +506,7 @@ def test_mfma_path_bit_exact(model, blob_default, n, path):
     assert any(w["silence"].any() for w, _ in cache.values()) and len(uniq) >= 2
 
 
+@both_profiles
 def test_mfma_and_vector_paths_agree_on_golden(model):
     g = golden("digest_default.npz")
     streams = (0, 1, 159, 4095)
@@ -493,6 +521,7 @@ def test_mfma_and_vector_paths_agree_on_golden(model):
         assert synth.crc32(b.export_state(i)) == int(g[f"s{s}_state_crc"])
 
 
+@both_profiles
 def test_mfma_sparser_model(blob_little):
     g = golden("digest_little.npz")
     m = capi.Model(blob_little)
@@ -565,3 +594,54 @@ def test_device_call_in_place(model, blob_default):
     b.process_device(buf.data_ptr(), buf.data_ptr(), 0, 0, T, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert_bits_equal(buf.cpu().numpy(), want["out"], "pcm in place")
+
+
+# ---- rcpps profiles (include/rnnoise_amd.h: rnnoise_amd_set_rcp_profile; reference: src/vec_avx.h:413,442,484,505) -------
+@pytest.mark.parametrize("profile", [pytest.param("amd-zen5", marks=pytest.mark.rcp("amd-zen5")),
+                                     pytest.param("host", marks=pytest.mark.rcp("host"))])
+def test_every_network_kernel_follows_the_rcp_profile(model, blob_default, profile):
+    """the three network schedules (vector, 16-stream MFMA tile, layer-wise) and the oracle on the SAME non-default profile:
+    identical bits -- and different from the Intel profile's, so the table really is what the kernels read"""
+    assert capi.rcp_profile().startswith(profile)
+    T, n = 24, 70
+    pcm = synth.batch_pcm([(5 * s) % 13 for s in range(n)], T, lead_silence=1)
+    want = {}
+    for path in (0, 1, 2):
+        b = capi.Batch(model, n)
+        b.set_nn_path(path)
+        out, vad, gains = b.process(pcm)
+        for s in (0, 1, 17, 64, 69):
+            if s not in want:
+                want[s] = Oracle(blob_default).run(pcm[:, s])
+            assert_bits_equal(gains[:, s], want[s]["gains"], f"{profile} path {path} gains stream {s}")
+            assert_bits_equal(vad[:, s], want[s]["vad"], f"{profile} path {path} vad stream {s}")
+            assert_bits_equal(out[:, s], want[s]["out"], f"{profile} path {path} pcm stream {s}")
+        b.close()
+    if not capi.rcp_profile().endswith("intel"):
+        from oracle import binding
+        binding.set_rcp_profile("intel")
+        other = Oracle(blob_default).run(pcm[:, 0])
+        assert not np.array_equal(other["gains"], want[0]["gains"])
+
+
+def test_profile_switch_reaches_live_batches(model, blob_default):
+    """rnnoise_amd_set_rcp_profile() replaces the table of every device that already holds one: a batch created before the
+    switch computes the next frames on the new profile (state carried over) -- checked against an oracle switched the same way"""
+    from oracle import binding
+    T = 10
+    pcm = synth.batch_pcm([2, 9, 4], 2 * T, lead_silence=0)
+    b = capi.Batch(model, 3)
+    o = [Oracle(blob_default) for _ in range(3)]
+    got1 = b.process(pcm[:T])
+    w1 = [o[s].run(pcm[:T, s]) for s in range(3)]
+    capi.set_rcp_profile("amd-zen5")
+    binding.set_rcp_profile("amd-zen5")
+    got2 = b.process(pcm[T:])
+    w2 = [o[s].run(pcm[T:, s]) for s in range(3)]
+    for s in range(3):
+        assert_bits_equal(got1[0][:, s], w1[s]["out"], f"before the switch, stream {s}")
+        assert_bits_equal(got2[0][:, s], w2[s]["out"], f"after the switch, stream {s}")
+        assert_bits_equal(got2[2][:, s], w2[s]["gains"], f"after the switch, gains {s}")
+    assert capi.rcp_profile() == "amd-zen5"
+    with pytest.raises(ValueError):
+        capi.set_rcp_profile("vax")

@@ -7,12 +7,13 @@ The reference ships no golden vectors; the pins are
 Bar: bit-exact on every float and integer, because the int8 quantisers amplify 1-ULP
 differences to >1e-4 gain differences.
 """
+import os
 import zlib
 
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal, golden, load_blob
+from conftest import both_profiles, ROOT, assert_bits_equal, golden, load_blob
 from oracle.binding import Oracle, RefHarness
 from rnnoise_amd import synth
 
@@ -21,6 +22,7 @@ def crc_rows(a):
     return np.array([zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xFFFFFFFF for r in a], np.uint32)
 
 
+@both_profiles
 def test_detail_golden(blob_default):
     g = golden("detail_default.npz")
     for s in (3, 77):
@@ -35,6 +37,7 @@ def test_detail_golden(blob_default):
         assert res["silence"][:12].all() and not res["silence"][13:].any()
 
 
+@both_profiles
 @pytest.mark.parametrize("s", [0, 1, 159, 4095])
 def test_digest_golden(blob_default, s):
     g = golden("digest_default.npz")
@@ -49,6 +52,7 @@ def test_digest_golden(blob_default, s):
     assert synth.crc32(o.get_state()) == int(g[f"s{s}_state_crc"])
 
 
+@both_profiles
 @pytest.mark.parametrize("case", ["loud", "dc", "impulses", "gaps"])
 def test_edge_golden(blob_default, case):
     g = golden("edge_default.npz")
@@ -62,6 +66,7 @@ def test_edge_golden(blob_default, case):
     assert synth.crc32(o.get_state()) == int(g[f"{case}_state_crc"])
 
 
+@both_profiles
 @pytest.mark.parametrize("s", [2, 31])
 def test_sparser_model_golden(blob_little, s):
     g = golden("digest_little.npz")
@@ -163,6 +168,61 @@ def test_activation_and_quantiser_edges():
     assert q.tolist() == [0, 0, 63, 127, 128, 190, 254, 255, 255, 0, 0]
 
 
+# ---- rcpps profiles (rnnoise_amd/csrc/rcp_profiles.h; reference: src/vec_avx.h:413,442,484,505) ------------------------
+def _rcp_table(name):
+    import re
+    txt = open(os.path.join(ROOT, "rnnoise_amd", "csrc", f"rcp_profile_{name}.h")).read()
+    return np.array([int(v) for v in re.findall(r"\d+", txt.split("{", 1)[1].split("}")[0])], np.uint32)
+
+
+def test_rcp_profiles_are_distinct_and_within_the_instruction_spec():
+    """both committed tables stay inside rcpps's documented error (|rel| <= 1.5 * 2^-12) and differ from each other in about
+    half of their entries by at most 2 units of 2^-12: the Intel-vs-AMD gap the drop-in has to follow"""
+    intel, amd = _rcp_table("intel"), _rcp_table("amd_zen5")
+    assert intel.size == 4096 and amd.size == 4096
+    x = 1 + np.arange(4096) / 4096
+    for t in (intel, amd):
+        r = ((t << 11) + 0x3f000000).astype(np.uint32).view(np.float32).astype(np.float64)
+        # checked at both ends of each table interval (the entry serves every x with the same top 12 mantissa bits)
+        assert max(np.abs(r * x - 1).max(), np.abs(r * (x + 1 / 4096) - 1).max()) <= 1.5 * 2.0 ** -12
+    d = amd.astype(int) - intel.astype(int)
+    assert 1500 < (d != 0).sum() < 3000 and np.abs(d).max() <= 2
+    assert np.array_equal(intel[0::2], intel[1::2]), "Intel's rcpps depends on 11 mantissa bits only"
+    assert not np.array_equal(amd[0::2], amd[1::2]), "Zen 5's needs all 12"
+
+
+@pytest.mark.parametrize("name", ["intel", "amd-zen5", "host"])
+def test_oracle_rcp_follows_the_selected_profile(name):
+    from oracle import binding
+    binding.set_rcp_profile(name)
+    L = Oracle.lib()
+    if name != "host":
+        t = _rcp_table(name.replace("-", "_"))
+        assert binding.rcp_profile() == name
+        for xb in (0x3f800000, 0x3f800800, 0x3fc00000 | (1234 << 11) | 77, 0x447a0000, 0x3a83126f):
+            want = ((int(t[(xb >> 11) & 0xfff]) << 11) + 0x3f000000 - ((xb & 0x7f800000) - 0x3f800000)) & 0xffffffff
+            got = np.float32(L.rno_rcp(float(np.uint32(xb).view(np.float32)))).view(np.uint32)
+            assert int(got) == want
+    else:  # this CPU: the captured table reproduces the instruction wherever we probe it (numpy has no rcpps; 1/x is within spec)
+        for v in (1.0, 1.37, 952.7, 1e-3, 6.02e4):
+            assert abs(L.rno_rcp(v) * v - 1) <= 1.5 * 2.0 ** -12
+
+
+def test_profiles_move_the_gains_by_less_than_the_activation_error(blob_default):
+    """measured size of the Intel-vs-AMD gap on a free-running stream (recorded in DESIGN.md section 2)"""
+    from oracle import binding
+    pcm = synth.stream_pcm(11, 120, lead_silence=3).astype(np.float32).reshape(120, 480)
+    binding.set_rcp_profile("intel")
+    a = Oracle(blob_default).run(pcm)
+    binding.set_rcp_profile("amd-zen5")
+    b = Oracle(blob_default).run(pcm)
+    dg = np.abs(a["gains"] - b["gains"])
+    assert 0 < dg.max() < 0.05 and not np.array_equal(a["out"], b["out"])
+    assert np.array_equal(a["features"][:5], b["features"][:5])  # the DSP front end does not depend on the profile
+    print(f"intel vs amd-zen5 over 120 frames: max |dgain| {dg.max():.2e}, mean {dg.mean():.2e}; "
+          f"max |dvad| {np.abs(a['vad'] - b['vad']).max():.2e}; max |dpcm| {np.abs(a['out'] - b['out']).max():.3f}")
+
+
 # ---- live reference (build container only) ---------------------------------------------------
 needs_ref = pytest.mark.skipif(not RefHarness.available(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -174,6 +234,7 @@ def test_tables_match_reference_bit_for_bit():
 
 
 @needs_ref
+@pytest.mark.rcp("host")  # the compiled reference executes this CPU's rcpps: the oracle must carry this CPU's table
 def test_live_reference_free_running(blob_default):
     pcm = synth.stream_pcm(11, 250, lead_silence=7).astype(np.float32).reshape(250, 480)
     o, r = Oracle(blob_default), RefHarness(blob_default)
@@ -198,6 +259,7 @@ def test_live_reference_fft_and_pitch():
 
 
 @needs_ref
+@pytest.mark.rcp("host")
 def test_live_reference_teacher_forced_state_import(blob_default):
     """state exported from the reference mid-stream drives the oracle to the same next frame"""
     pcm = synth.stream_pcm(21, 60).astype(np.float32).reshape(60, 480)

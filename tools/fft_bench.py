@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from oracle.binding import Oracle  # noqa: E402  (checker)
 from rnnoise_amd import capi  # noqa: E402
 
-L = capi.lib()
+L = capi.instrumented().__enter__()  # probe kernels: librnnoise_amd_instr.so
 rng = np.random.Generator(np.random.PCG64(5))
 
 

@@ -8,6 +8,7 @@ from rnnoise_amd import capi, synth
 NAMES = ["load", "-", "win+FFT(X)+Ex", "downsample+FIR", "coarse xcorr", "coarse scan", "fine xcorr",
          "fine select", "doubling dots", "Syy+yy sweeps", "decide", "P FFT+Ep+Exp+feat"]
 blob = lzma.decompress(open(os.path.join(ROOT, "tests/golden/default.blob.xz"), "rb").read())
+capi.instrumented().__enter__()  # the taps are compiled into librnnoise_amd_instr.so only
 m = capi.Model(blob)
 for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
     b = capi.Batch(m, n)
