@@ -394,9 +394,20 @@ struct AnalysisLds {
 #define MAIL_BP1 2
 #define MAIL_XX 3      //   <x, x> of remove_doubling
 #define MAIL_SYY0F 4   //   start energy of the fine find_best_pitch
+// K1_STOP(k): instrumented build only -- the whole workgroup leaves the kernel at stop point k (tools/k1_prefix.sh runs the
+// kernel once per stop point under the PMC counters: the differences are each section's LDS cycles, bank conflicts, VALU
+// instructions and time).  Stop points sit where all waves of a workgroup pass together.
+#if RN_INSTRUMENT
+#define K1_STOP(k) do { if (k1_stop == (k)) return; } while (0)
+#else
+#define K1_STOP(k) do { } while (0)
+#endif
 template <bool TRAIN, int SPW>
-__device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot, int parity,
+__device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot_arg, int parity,
                                               const RnTrainArgs &tr) {
+  const int slot = slot_arg & 255;
+  const int k1_stop = RN_INSTRUMENT ? (slot_arg >> 16) : 0;
+  (void)k1_stop;
   const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw);
@@ -460,7 +471,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   {
     float xr[15], xi[15];
     window_to_regs(xr, xi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE, tb.half_window);
+    K1_STOP(1);
     regfft960<RN_FFT_XLANE>(xr, xi, lane, ftw);
+    K1_STOP(2);
     if (TRAIN) {  // band limit of the TRAINING build (src/denoise.c:340-343)
       const int lp = tr.lowpass[s];
 #pragma unroll
@@ -477,6 +490,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   band_chain(Ex, Qs, sums, tb, lane);
 
   CLK_TAP(2);  // window + FFT(X) + Ex
+  K1_STOP(3);
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
 #pragma unroll 7
   for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
@@ -518,6 +532,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   RN_WSYNC();
 
   CLK_TAP(3);  // downsample + autocorr + LPC + FIR
+  K1_STOP(4);
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC;
@@ -530,6 +545,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     RN_WSYNC();
     // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
     const v2f p = chain_dot8_x2(y4 + 192, Z + lane, 240);
+    K1_STOP(5);
     // lanes 0..18: lags 128..146; lane 19: the start energy 1 + sum y4[j]^2 of the coarse find_best_pitch
     float q = 0;
     if (lane < 20) q = chain_dot8(lane < 19 ? y4 + 192 : y4, lane < 19 ? y4 + lane + 128 : y4, 240, lane < 19 ? 0.f : 1.f);
@@ -542,6 +558,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   RN_WSYNC();
   int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
+  K1_STOP(6);
   float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
   fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
   if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
@@ -553,6 +570,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   WG_SYNC();
   best_pitch_select(xc, scr + SCR_SYY, 147, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
+  K1_STOP(7);
   if (dbg) {
     for (int i = lane; i < 147; i += WAVE) dbg[RN_DBG_XC_COARSE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST] = bp0; dbg[RN_DBG_BEST + 1] = bp1; }
@@ -565,6 +583,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     mail[MAIL_BP0] = __int_as_float(bp0);
     mail[MAIL_BP1] = __int_as_float(bp1);
   }
+  K1_STOP(8);
   WG_SYNC();
   if (wave == 0) {
     // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
@@ -599,9 +618,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps of the whole workgroup (wave 0's view)
   }
   WG_SYNC();
+  K1_STOP(9);
   const float xx = mail[MAIL_XX];
   best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch selection
+  K1_STOP(10);
   int offset = 0;
   if (bp0 > 0 && bp0 < 293) {
     float a = xc[bp0 - 1], b = xc[bp0], c = xc[bp0 + 1];
@@ -657,6 +678,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       }
     }
     RN_WSYNC();
+    K1_STOP(11);
     // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
     // independent serial sum, so computing it speculatively changes no bit):
     //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
@@ -686,6 +708,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     RN_WSYNC();
     float xy = dots[1];
     CLK_TAP(8);  // 59 candidate dot products of remove_doubling
+    K1_STOP(12);
     float yy = yyl[T0];
     float best_xy = xy, best_yy = yy;
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
@@ -750,6 +773,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
 
   CLK_TAP(10);  // doubling decisions + 3 final dots
+  K1_STOP(13);
   // ---- pitch-aligned frame -> P, Ep, Exp (src/denoise.c:371-377) ----
   float dctc[RN_NB_BANDS];  // this lane's DCT column, requested now, consumed after the band energies
   {
@@ -771,7 +795,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
 #pragma unroll
     for (int j = 0; j < RN_NB_BANDS; j++) dctc[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
+    K1_STOP(14);
     regfft960<RN_FFT_XLANE>(pr, pi, lane2, ftw2);
+    K1_STOP(15);
     float *gP = g.spec_P[parity] + (size_t)s * RN_SPEC_STRIDE;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -783,6 +809,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     band_products(Qs, xr, xi, pr, pi, tb, pos);
   }
   band_chain(Exp, Qs, sums, tb, lane);
+  K1_STOP(16);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
     Exp[lane] = (float)((double)Exp[lane] / sqrt(.001 + (double)(Ex[lane] * Ep[lane])));
@@ -894,7 +921,7 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
   // one of them per SIMD, always ready with an old instruction, otherwise takes issue slots from four analysis waves
   // (29.14 -> 29.41 M frames/s at 65,536 streams; RNNOISE_AMD_K1_PRIO=0 switches it off for A/B runs).
   if (slot & 256) __builtin_amdgcn_s_setprio(1);
-  analysis_body<false, K1_SPW>(g, tb, slot & 255, parity, RnTrainArgs{});
+  analysis_body<false, K1_SPW>(g, tb, slot & ~256, parity, RnTrainArgs{});
 }
 // One stream per workgroup: batches that fit in one round of resident waves (<= 16 per CU) are bound by a wave's latency,
 // not by instruction issue, and there the narrow phases are better run by every wave for itself.  Measured on MI355X
@@ -1085,7 +1112,8 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
   } else {
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
     static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio, parity);
+    static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop, parity);
   }
   return hipGetLastError();
 }

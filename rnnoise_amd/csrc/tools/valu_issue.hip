@@ -21,11 +21,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 enum Op { FMA32, ADD32, MUL32, ADD32_DPP_ROWSHR, ADD32_DPP_QUAD, MOV_DPP_ROWROR, PKADD32, PKFMA32, PKMUL32, FMA64, ADD64, MUL64, DOT4, ADDU32, MADU24,
-          MED3, CVTPKU8, RCP32, EXP32, PERM, CNDMASK, CMP32, DSREAD32, DSREAD64, DSREAD128, DSSWIZZLE, DSBPERMUTE, PERMLANE32SWAP, FMA32_DSREAD, FMA32_SALU, NOPS };
+          MED3, CVTPKU8, RCP32, EXP32, PERM, CNDMASK, CMP32, DSREAD32, DSREAD64, DSREAD128, DSSWIZZLE, DSBPERMUTE, PERMLANE32SWAP, FMA32_DSREAD, FMA32_SALU, NOPS,
+          MOV32, AND32, LSHL32, XOR32, MAX32, SUB32, CNDMASK_S, CMP_S, BFE32, LSHLADD, READLANE, MULLO, ADD32_SGPR, MUL32_LIT, DSWRITE32, DSWRITE128, DSREADU16, DPP_WAVESHR, ADD3 };
 static const char *OPN[] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_f32 dpp row_shr:1", "v_add_f32 dpp quad_perm", "v_mov_b32 dpp row_ror:8", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mul_f32",
                             "v_fma_f64", "v_add_f64", "v_mul_f64", "v_dot4_i32_i8", "v_add_u32", "v_mad_u32_u24", "v_med3_f32", "v_cvt_pk_u8_f32", "v_rcp_f32", "v_exp_f32", "v_perm_b32",
                             "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b32", "ds_read_b64", "ds_read_b128", "ds_swizzle_b32", "ds_bpermute_b32", "v_permlane32_swap", "v_fma_f32 + ds_read_b32 (1:1)",
-                            "v_fma_f32 + s_add_u32 (1:1)", "s_nop 0"};
+                            "v_fma_f32 + s_add_u32 (1:1)", "s_nop 0",
+                            "v_mov_b32", "v_and_b32", "v_lshlrev_b32", "v_xor_b32", "v_max_f32", "v_sub_f32", "v_cndmask_b32 (sgpr mask)", "v_cmp_lt_f32 -> sgpr pair", "v_bfe_u32", "v_lshl_add_u32",
+                            "v_readlane_b32", "v_mul_lo_u32", "v_add_f32 (sgpr operand)", "v_mul_f32 (literal)", "ds_write_b32", "ds_write_b128", "ds_read_u16", "v_add_f32 dpp wave_shr:1", "v_add3_u32"};
 constexpr int UNROLL = 64;
 
 // UNROLL = 64 instructions on 8 (or 1, NACC == 1) accumulators, as ONE asm statement (hipcc puts an s_nop after every
@@ -38,10 +41,10 @@ constexpr int UNROLL = 64;
   do {                                                                                                                           \
     if constexpr (NACC == 8)                                                                                                     \
       asm volatile(G8(T) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])        \
-                   : [c0] "v"(c0), [c1] "v"(c1), [ad] "v"(lds_addr) : "vcc", "s20", "scc");                                      \
+                   : [c0] "v"(c0), [c1] "v"(c1), [ad] "v"(lds_addr), [ad2] "v"(lds_addr * 2) : "vcc", "s20", "s22", "s23", "s24", "scc");  \
     else                                                                                                                         \
       asm volatile(G1(T) : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])        \
-                   : [c0] "v"(c0), [c1] "v"(c1), [ad] "v"(lds_addr) : "vcc", "s20", "scc");                                      \
+                   : [c0] "v"(c0), [c1] "v"(c1), [ad] "v"(lds_addr), [ad2] "v"(lds_addr * 2) : "vcc", "s20", "s22", "s23", "s24", "scc");  \
   } while (0)
 #define T_FMA32(n) "v_fma_f32 %" #n ", %" #n ", %[c0], %[c1]\n"
 #define T_ADD32(n) "v_add_f32 %" #n ", %" #n ", %[c0]\n"
@@ -66,13 +69,31 @@ constexpr int UNROLL = 64;
 #define T_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %[c0], vcc\n"
 #define T_CMP(n) "v_cmp_lt_f32 vcc, %" #n ", %[c0]\n"
 #define T_DSR32(n) "ds_read_b32 %" #n ", %[ad]\n"
-#define T_DSR64(n) "ds_read_b64 %" #n ", %[ad]\n"
+#define T_DSR64(n) "ds_read_b64 %" #n ", %[ad2]\n"
 #define T_DSSWZ(n) "ds_swizzle_b32 %" #n ", %" #n " offset:0x401f\n"
 #define T_DSBPERM(n) "ds_bpermute_b32 %" #n ", %[ad], %" #n "\n"
 #define T_PL32(n) "v_permlane32_swap_b32 %" #n ", %7\n"
 #define T_FMADS(n) "v_fma_f32 %" #n ", %" #n ", %[c0], %[c1]\n ds_read_b32 %7, %[ad]\n"
 #define T_FMASALU(n) "v_fma_f32 %" #n ", %" #n ", %[c0], %[c1]\n s_add_u32 s20, s20, 1\n"
 #define T_NOP(n) "s_nop 0\n"
+#define T_MOV(n) "v_mov_b32 %" #n ", %[c0]\n"
+#define T_AND(n) "v_and_b32 %" #n ", %" #n ", %[ad]\n"
+#define T_LSHL(n) "v_lshlrev_b32 %" #n ", 1, %" #n "\n"
+#define T_XOR(n) "v_xor_b32 %" #n ", %" #n ", %[ad]\n"
+#define T_MAX(n) "v_max_f32 %" #n ", %" #n ", %[c0]\n"
+#define T_SUB(n) "v_sub_f32 %" #n ", %" #n ", %[c0]\n"
+#define T_CNDS(n) "v_cndmask_b32 %" #n ", %" #n ", %[c0], s[22:23]\n"
+#define T_CMPS(n) "v_cmp_lt_f32 s[22:23], %" #n ", %[c0]\n"
+#define T_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 3, 12\n"
+#define T_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 3, %[ad]\n"
+#define T_READLANE(n) "v_readlane_b32 s20, %" #n ", 5\n"
+#define T_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %[ad]\n"
+#define T_ADDS(n) "v_add_f32 %" #n ", s24, %" #n "\n"
+#define T_MULLIT(n) "v_mul_f32 %" #n ", 0x3f8ccccd, %" #n "\n"
+#define T_DSW32(n) "ds_write_b32 %[ad], %" #n "\n"
+#define T_DSRU16(n) "ds_read_u16 %" #n ", %[ad]\n"
+#define T_WAVESHR(n) "v_add_f32_dpp %" #n ", %" #n ", %[c0] wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define T_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %[ad], %[ad]\n"
 template <int OP, int NACC>
 __device__ __forceinline__ void body(float (&a)[8], v2f (&p)[8], double (&d)[8], int (&n)[8], v4f (&q)[8], float c0, float c1, int lds_addr) {
   if constexpr (OP == FMA32) EMIT(T_FMA32, a);
@@ -109,7 +130,29 @@ __device__ __forceinline__ void body(float (&a)[8], v2f (&p)[8], double (&d)[8],
   if constexpr (OP == FMA32_DSREAD) EMIT(T_FMADS, a);
   if constexpr (OP == FMA32_SALU) EMIT(T_FMASALU, a);
   if constexpr (OP == NOPS) EMIT(T_NOP, a);
-  if constexpr (OP == DSREAD32 || OP == DSREAD64 || OP == DSREAD128 || OP == DSSWIZZLE || OP == DSBPERMUTE || OP == FMA32_DSREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (OP == MOV32) EMIT(T_MOV, a);
+  if constexpr (OP == AND32) EMIT(T_AND, n);
+  if constexpr (OP == LSHL32) EMIT(T_LSHL, n);
+  if constexpr (OP == XOR32) EMIT(T_XOR, n);
+  if constexpr (OP == MAX32) EMIT(T_MAX, a);
+  if constexpr (OP == SUB32) EMIT(T_SUB, a);
+  if constexpr (OP == CNDMASK_S) EMIT(T_CNDS, a);
+  if constexpr (OP == CMP_S) EMIT(T_CMPS, a);
+  if constexpr (OP == BFE32) EMIT(T_BFE, n);
+  if constexpr (OP == LSHLADD) EMIT(T_LSHLADD, n);
+  if constexpr (OP == READLANE) EMIT(T_READLANE, a);
+  if constexpr (OP == MULLO) EMIT(T_MULLO, n);
+  if constexpr (OP == ADD32_SGPR) EMIT(T_ADDS, a);
+  if constexpr (OP == MUL32_LIT) EMIT(T_MULLIT, a);
+  if constexpr (OP == DSWRITE32) EMIT(T_DSW32, a);
+  if constexpr (OP == DSWRITE128) {
+    for (int u = 0; u < 8; u++) asm volatile("ds_write_b128 %8, %0\n ds_write_b128 %8, %1\n ds_write_b128 %8, %2\n ds_write_b128 %8, %3\n ds_write_b128 %8, %4\n ds_write_b128 %8, %5\n ds_write_b128 %8, %6\n ds_write_b128 %8, %7\n"
+                 : : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]), "v"(lds_addr * 4) : "memory");
+  }
+  if constexpr (OP == DSREADU16) EMIT(T_DSRU16, n);
+  if constexpr (OP == DPP_WAVESHR) EMIT(T_WAVESHR, a);
+  if constexpr (OP == ADD3) EMIT(T_ADD3, n);
+  if constexpr (OP == DSREAD32 || OP == DSREAD64 || OP == DSREAD128 || OP == DSSWIZZLE || OP == DSBPERMUTE || OP == FMA32_DSREAD || OP == DSWRITE32 || OP == DSWRITE128 || OP == DSREADU16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 template <int OP, int NACC>
@@ -217,5 +260,8 @@ int main() {
   row<PERM>(dT, dS, it); row<CNDMASK>(dT, dS, it); row<CMP32>(dT, dS, it);
   row<DSREAD32>(dT, dS, it); row<DSREAD64>(dT, dS, it); row<DSREAD128>(dT, dS, it); row<DSSWIZZLE>(dT, dS, it); row<DSBPERMUTE>(dT, dS, it); row<PERMLANE32SWAP>(dT, dS, it);
   row<FMA32_DSREAD>(dT, dS, it); row<FMA32_SALU>(dT, dS, it); row<NOPS>(dT, dS, it);
+  row<MOV32>(dT, dS, it); row<AND32>(dT, dS, it); row<LSHL32>(dT, dS, it); row<XOR32>(dT, dS, it); row<MAX32>(dT, dS, it); row<SUB32>(dT, dS, it); row<CNDMASK_S>(dT, dS, it);
+  row<CMP_S>(dT, dS, it); row<BFE32>(dT, dS, it); row<LSHLADD>(dT, dS, it); row<ADD3>(dT, dS, it); row<READLANE>(dT, dS, it); row<MULLO>(dT, dS, it); row<ADD32_SGPR>(dT, dS, it);
+  row<MUL32_LIT>(dT, dS, it); row<DPP_WAVESHR>(dT, dS, it); row<DSWRITE32>(dT, dS, it); row<DSWRITE128>(dT, dS, it); row<DSREADU16>(dT, dS, it);
   return 0;
 }
