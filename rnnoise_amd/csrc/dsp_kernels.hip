@@ -161,14 +161,17 @@ __device__ __forceinline__ void fbp_increments(const float *y, int len, int max_
 __device__ __forceinline__ void fbp_sweep(float *syy, int max_pitch, float Syy0, bool store) {
   const int mp4 = (max_pitch + 3) & ~3;
   float Syy = Syy0;
+  float4 d = *reinterpret_cast<const float4 *>(syy);
   for (int i = 0; i < mp4; i += 4) {
-    const float4 d = *reinterpret_cast<const float4 *>(syy + i);
+    // the next four increments are requested before this block's dependent adds: the LDS round trip is off the chain
+    const float4 dn = *reinterpret_cast<const float4 *>(syy + (i + 4 < mp4 ? i + 4 : i));
     float4 o;
     o.x = Syy; Syy = fmaxf(1.f, Syy + d.x);  // MAX32(1, Syy): same value for every non-NaN Syy
     o.y = Syy; Syy = fmaxf(1.f, Syy + d.y);
     o.z = Syy; Syy = fmaxf(1.f, Syy + d.z);
     o.w = Syy; Syy = fmaxf(1.f, Syy + d.w);
     if (store) *reinterpret_cast<float4 *>(syy + i) = o;
+    d = dn;
   }
 }
 
@@ -236,21 +239,37 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // 
     }                                                                        \
   } while (0)
 
+// ---- LDS pointers with their address space spelled out.  The chains below take their operands through pointers picked per
+// lane (this stream's arena or another's, the signal or its shifted copy); when such a pointer reaches a load as a generic
+// one the compiler emits flat_load, which the LDS serves at a fraction of a ds_read's rate (round 2's doubling dots and
+// fine-search chains ran on flat loads: 9-12 LDS cycles per instruction, profiles/r3_k1_sections_before.txt).
+#define LDS_AS __attribute__((address_space(3)))
+typedef const LDS_AS float *ldsf;
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define OPAQUE(v) asm("" : "+v"(v))
+__device__ __forceinline__ ldsf to_lds(const float *p) { return (ldsf)p; }
+__device__ __forceinline__ v4f_ lds_read16(ldsf p) { return *(const LDS_AS v4f_ *)p; }
+// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave, 256 B/clk): left alone, the load-store optimiser
+// fuses neighbouring ones into ds_read2_b64, which the LDS serves at half that rate (8 cycles per instruction,
+// MI355X_MICROARCH.md section LDS) -- in the chains below that doubled the cycles of the operand stream.
+__device__ __forceinline__ v2f lds_read8(ldsf p) { return *(const volatile LDS_AS v2f *)p; }
+
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
 // x 16-byte aligned, y arbitrary; both may differ per lane.  The next 8 operand pairs are fetched
 // from LDS while the current 8 are being added, so the LDS round trip is off the chain.
 // s0 is the chain's start value: a lane with x == y and s0 = 1 computes a find_best_pitch start
 // energy 1 + sum y[j]^2 (src/pitch.c:56-61) in the same instructions as the real dot products.
-#define OPAQUE(v) asm("" : "+v"(v))
-__device__ __forceinline__ float chain_dot8(const float *x, const float *y, int n, float s0 = 0.f) {
+__device__ __forceinline__ float chain_dot8(ldsf x, ldsf y, int n, float s0 = 0.f) {
   float s = s0;
-  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
+  v4f_ xa = lds_read16(x), xb = lds_read16(x + 4);
   float ya[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) ya[k] = y[k];
+#pragma unroll 2
   for (int i = 0; i < n; i += 8) {
     const int nx = (i + 8 < n) ? i + 8 : i;
-    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
+    const v4f_ xc = lds_read16(x + nx), xd = lds_read16(x + nx + 4);
     float yn[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) yn[k] = y[nx + k];
@@ -278,18 +297,19 @@ __device__ __forceinline__ float chain_dot8(const float *x, const float *y, int 
 // chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
 // For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
 // dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
-__device__ __forceinline__ float chain_dot8_y2(const float *x, const float *y2, int n) {
+__device__ __forceinline__ float chain_dot8_y2(ldsf x, ldsf y2, int n) {
   float s = 0.f;
-  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
-  float2 ya[4];
+  v4f_ xa = lds_read16(x), xb = lds_read16(x + 4);
+  v2f ya[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) ya[k] = *reinterpret_cast<const float2 *>(y2 + 2 * k);
+  for (int k = 0; k < 4; k++) ya[k] = lds_read8(y2 + 2 * k);
+#pragma unroll 2
   for (int i = 0; i < n; i += 8) {
     const int nx = (i + 8 < n) ? i + 8 : i;
-    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
-    float2 yn[4];
+    const v4f_ xc = lds_read16(x + nx), xd = lds_read16(x + nx + 4);
+    v2f yn[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) yn[k] = *reinterpret_cast<const float2 *>(y2 + nx + 2 * k);
+    for (int k = 0; k < 4; k++) yn[k] = lds_read8(y2 + nx + 2 * k);
     float p0 = xa.x * ya[0].x, p1 = xa.y * ya[0].y, p2 = xa.z * ya[1].x, p3 = xa.w * ya[1].y;
     float p4 = xb.x * ya[2].x, p5 = xb.y * ya[2].y, p6 = xb.z * ya[3].x, p7 = xb.w * ya[3].y;
     OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
@@ -313,43 +333,62 @@ __device__ __forceinline__ float chain_dot8_y2(const float *x, const float *y2, 
 // (float offsets, the SCR_* constants below):
 //   FFT phases   : F = [0,2160) (960 complex, padded layout); the band products Q live in [1084,1948),
 //                  above the 481 bins that matter; small per-frame vectors in [2392,2560)
-//   coarse search: xlp [0,864) | y4 [1296,1728) | interleaved pairs Z [1728,2334)
-//                  during the 147 chains, then running energies [1728,1876) and xcorr [2028,2175)
+//   coarse search: xlp [0,864) | y4 [864,1296) | y4 shifted by one [1344,1730) | interleaved pairs Z [1732,2310)
+//                  during the chains, then running energies [1728,1876) and xcorr [2028,2175)
 //   fine search  : xlp | reversed squares -> yy_lookup [864,1728) | energy increments -> Syy [1731,2028)
-//                  | xcorr [2028,2324) | 4 zeros [2324,2328); the 64 doubling dots reuse [2120,2184)
-// two independent dot-product chains per lane (lags l and l+64 against the same x): the pair is
-// written as 2-wide vector arithmetic so that it compiles to v_pk_mul_f32 / v_pk_add_f32 -- half the
-// VALU instructions of two scalar chains; each component is still mul-then-add in the reference order.
-// z[k] = {y[k], y[k+64]} comes from an interleaved copy, so a pair is one 8-byte LDS read that lands
-// in an aligned register pair (built from two arrays the pairs cost ~2.5 moves per step).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f chain_dot8_x2(const float *x, const v2f *z, int n) {
-  v2f s = {0.f, 0.f};
-  float4 xa = *reinterpret_cast<const float4 *>(x), xb = *reinterpret_cast<const float4 *>(x + 4);
-  v2f y[8];
+//                  | xcorr [2028,2324) | 4 zeros [2324,2328); the doubling dots reuse [2120,2184)
+// Three chains per lane against the same x: two lags as a 2-wide vector chain -- it compiles to v_pk_mul_f32 /
+// v_pk_add_f32, each component still mul-then-add in the reference order; z[k] = {y[k], y[k+49]} comes from an interleaved
+// copy, so a pair is one 8-byte LDS read that lands in an aligned register pair -- plus a scalar chain whose y operand comes
+// two steps per LDS instruction from y2 (8-byte aligned; the caller points odd offsets into a copy shifted by one sample).
+// One pass of this over 49 lanes x 3 lags (+ one lane for the start energy) replaces the 64 x 2 pass and the 20-lane
+// second pass of the coarse search.
+struct XC3 { v2f p; float q; };
+__device__ __forceinline__ XC3 chain_dot8_x3(ldsf x, ldsf z, ldsf y2, int n, v2f s0) {
+  v2f s = s0;
+  float q = 0.f;
+  v4f_ xa = lds_read16(x), xb = lds_read16(x + 4);
+  v2f y[8], w[4];
 #pragma unroll
-  for (int k = 0; k < 8; k++) y[k] = z[k];
+  for (int k = 0; k < 8; k++) y[k] = lds_read8(z + 2 * k);
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = lds_read8(y2 + 2 * k);
 #pragma unroll 2
   for (int i = 0; i < n; i += 8) {
     const int nx = (i + 8 < n) ? i + 8 : i;
-    const float4 xc = *reinterpret_cast<const float4 *>(x + nx), xd = *reinterpret_cast<const float4 *>(x + nx + 4);
-    v2f yn[8];
+    const v4f_ xc = lds_read16(x + nx), xd = lds_read16(x + nx + 4);
+    v2f yn[8], wn[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) yn[k] = z[nx + k];
+    for (int k = 0; k < 8; k++) yn[k] = lds_read8(z + 2 * (nx + k));
+#pragma unroll
+    for (int k = 0; k < 4; k++) wn[k] = lds_read8(y2 + nx + 2 * k);
+    float p0 = xa.x * w[0].x, p1 = xa.y * w[0].y, p2 = xa.z * w[1].x, p3 = xa.w * w[1].y;
+    float p4 = xb.x * w[2].x, p5 = xb.y * w[2].y, p6 = xb.z * w[3].x, p7 = xb.w * w[3].y;
+    OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
     s = s + v2f{xa.x, xa.x} * y[0];
+    q = q + p0;
     s = s + v2f{xa.y, xa.y} * y[1];
+    q = q + p1;
     s = s + v2f{xa.z, xa.z} * y[2];
+    q = q + p2;
     s = s + v2f{xa.w, xa.w} * y[3];
+    q = q + p3;
     s = s + v2f{xb.x, xb.x} * y[4];
+    q = q + p4;
     s = s + v2f{xb.y, xb.y} * y[5];
+    q = q + p5;
     s = s + v2f{xb.z, xb.z} * y[6];
+    q = q + p6;
     s = s + v2f{xb.w, xb.w} * y[7];
+    q = q + p7;
     xa = xc;
     xb = xd;
 #pragma unroll
     for (int k = 0; k < 8; k++) y[k] = yn[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = wn[k];
   }
-  return s;
+  return XC3{s, q};
 }
 
 struct AnalysisLds {
@@ -360,8 +399,10 @@ struct AnalysisLds {
 };
 #define SCR_XLP 0
 #define SCR_SQ 864    // [864]  fine search: reversed squares of xlp, later yy_lookup
-#define SCR_Y4 1296   // [432]  4x-decimated signal (coarse search only)
-#define SCR_Z 1728    // [606]  {y4[j], y4[j+64]} pairs for the packed coarse chains
+#define SCR_Y4 864    // [432]  4x-decimated signal (coarse search only; over the not yet written squares)
+#define SCR_Y4S 1344  // [386]  the same shifted by one sample (8-byte reads at odd offsets); 480 floats after y4: the two copies'
+                      //        8-byte slots interleave, so even and odd lanes of one read do not collide
+#define SCR_Z 1732    // [578]  {y4[k], y4[k+49]} pairs for the packed coarse chains
 #define SCR_SYY 1728  // [148]  running energies of the coarse find_best_pitch
 #define SCR_D 1732    // [-1..295] fine search: Syy increments, then Syy itself (16-byte aligned)
 #define SCR_XC 2028   // [296]  xcorr[] of pitch_search
@@ -537,23 +578,41 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC;
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
-  for (int j = lane; j < 432; j += WAVE) y4[j] = xlp[2 * j];
   float syy0_coarse;
   {
+    float *y4s = scr + SCR_Y4S;
     v2f *Z = reinterpret_cast<v2f *>(scr + SCR_Z);
-    for (int j = lane; j < 303; j += WAVE) Z[j] = v2f{xlp[2 * j], xlp[2 * j + 128]};
+#pragma unroll
+    for (int t = 0; t < 7; t++) {  // 432 = 6.75 x 64; clamped, not branched
+      const int j0 = lane + WAVE * t, j = j0 < 432 ? j0 : 431;
+      const float v = xlp[2 * j];
+      y4[j] = v;
+      if (j >= 1) y4s[j - 1] = v;  // y4s[i] = y4[i + 1] (only i < 386 is read)
+    }
+#pragma unroll
+    for (int t = 0; t < 5; t++) {  // 289 pairs
+      const int j0 = lane + WAVE * t, j = j0 < 289 ? j0 : 288;
+      Z[j] = v2f{xlp[2 * j], xlp[2 * j + 98]};
+    }
     RN_WSYNC();
-    // 147 lags: lanes take lags (l, l+64) as a packed pair, then the 19 lags 128..146
-    const v2f p = chain_dot8_x2(y4 + 192, Z + lane, 240);
+    // ONE pass for the 147 lags and the start energy: a lane takes lags l3 and l3 + 49 as a packed pair and lag l3 + 98 as a
+    // scalar chain, l3 = 0..48 on lanes 0..30 and 32..49; lane 31 runs 1 + sum y4[j]^2 (src/pitch.c:56-61) as the first
+    // chain of its pair -- its x operand is y4 itself and its pairs start at Z[0] = {y4[0], ..}, the address lane 0 of the
+    // same 32-lane access group reads anyway (a broadcast, not a bank conflict).  Lanes 50..63 repeat lanes 35..48 of their
+    // own group, for the same reason, and are not stored.
+    const bool en = lane == 31, stored = lane < 50 && !en;
+    const int l3 = en ? 0 : (lane < 31 ? lane : (lane < 50 ? lane - 1 : lane - 15));
+    const int a3 = l3 + 98;  // offset of the scalar chain: y4[a3 + j], fetched 8 bytes at a time from the copy that aligns it
+    const XC3 r = chain_dot8_x3(to_lds(scr + (en ? SCR_Y4 : SCR_Y4 + 192)), to_lds(scr + (en ? SCR_Z : SCR_Z + 2 * l3)),
+                                to_lds(scr + ((a3 & 1) ? SCR_Y4S + (a3 - 1) : SCR_Y4 + a3)), 240, en ? v2f{1.f, 0.f} : v2f{0.f, 0.f});
     K1_STOP(5);
-    // lanes 0..18: lags 128..146; lane 19: the start energy 1 + sum y4[j]^2 of the coarse find_best_pitch
-    float q = 0;
-    if (lane < 20) q = chain_dot8(lane < 19 ? y4 + 192 : y4, lane < 19 ? y4 + lane + 128 : y4, 240, lane < 19 ? 0.f : 1.f);
     RN_WSYNC();  // Z is dead; xcorr goes into its area
-    xc[lane] = p.x;
-    xc[lane + 64] = p.y;
-    if (lane < 147 - 128) xc[lane + 128] = q;
-    syy0_coarse = lane_bcast(q, 19);
+    if (stored) {
+      xc[l3] = r.p.x;
+      xc[l3 + 49] = r.p.y;
+      xc[l3 + 98] = r.q;
+    }
+    syy0_coarse = lane_bcast(r.p.x, 31);
   }
   RN_WSYNC();
   int bp0, bp1;
@@ -564,8 +623,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
   WG_SYNC();
   if (wave == 0) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
+    // The other waves of the workgroup wait for this one, and its chains are dependent instructions: it takes every issue
+    // slot it can use (a lone wave issues once per ~5 cycles whatever its priority; profiles/r3_valu_issue.txt) ahead of the
+    // three waves of other workgroups on its SIMD, which have independent work for the remaining slots.
+    if (SPW > 1) __builtin_amdgcn_s_setprio(3);
     const int gi = lane < SPW ? lane : 0;
     fbp_sweep(arenas[gi].a + SCR_SYY, 147, arenas[gi].a[SCR_MAIL + MAIL_SYY0C], lane < SPW);
+    if (SPW > 1) __builtin_amdgcn_s_setprio(1);
   }
   WG_SYNC();
   best_pitch_select(xc, scr + SCR_SYY, 147, bp0, bp1, lane);
@@ -586,11 +650,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   K1_STOP(8);
   WG_SYNC();
   if (wave == 0) {
+    if (SPW > 1) __builtin_amdgcn_s_setprio(3);
     // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
     // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch
     {
-      const int gq = lane / 12, r = lane - 12 * gq;
-      const bool on = gq < SPW;
+      // (two streams per 32-lane LDS access group: the per-lane-offset reads of a group then collide among 2 arenas' clusters
+      //  instead of 3; lanes 24..31 and 56..63 idle)
+      const int l5 = lane & 31, gq = 2 * (lane >> 5) + (l5 >= 12 ? 1 : 0), r = l5 - 12 * (l5 >= 12 ? 1 : 0);
+      const bool on = gq < SPW && l5 < 24;
       const int gi = on ? gq : 0;
       float *xlp_g = arenas[gi].a + SCR_XLP, *xc_g = arenas[gi].a + SCR_XC, *mail_g = arenas[gi].a + SCR_MAIL;
       const int b0 = __float_as_int(mail_g[MAIL_BP0]), b1 = __float_as_int(mail_g[MAIL_BP1]);
@@ -598,7 +665,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const bool lag = on && r < 10 && c >= 0 && c < 294;
       float sum = 0;
       if (lag || (on && r >= 10))
-        sum = chain_dot8(r == 11 ? xlp_g : xlp_g + 384, lag ? xlp_g + c : (r == 11 ? xlp_g : xlp_g + 384), 480,
+        sum = chain_dot8(to_lds(xlp_g + (r == 11 ? 0 : 384)), to_lds(xlp_g + (lag ? c : (r == 11 ? 0 : 384))), 480,
                          r == 11 ? 1.f : 0.f);
       if (lag) xc_g[c] = (-1 > sum) ? -1 : sum;
       if (on && r == 10) mail_g[MAIL_XX] = sum;
@@ -616,6 +683,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       energy_sweeps_run(a + SCR_SQ, a + SCR_D, a + SCR_ZERO, mail_g[MAIL_SYY0F], mail_g[MAIL_XX], role, on);
     }
     CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps of the whole workgroup (wave 0's view)
+    if (SPW > 1) __builtin_amdgcn_s_setprio(1);
   }
   WG_SYNC();
   K1_STOP(9);
@@ -679,12 +747,15 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     RN_WSYNC();
     K1_STOP(11);
-    // every dot product the routine can ask for, in ONE pass of 480-step chains (each chain is an
-    // independent serial sum, so computing it speculatively changes no bit):
-    //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);
-    //   lanes 32..61: the +-1 neighbours of every period the decision loop can end on
-    //   (T0 and T1(k)), needed by the final 3-point refinement (pitch.c:511-512).
+    // Every dot product the decision loop can ask for, in ONE pass of 480-step chains on the first 32 lanes (each chain
+    // is an independent serial sum, so computing it speculatively changes no bit):
+    //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  lanes 30, 31: the -1 / +1 neighbours of T0,
+    //   which the final 3-point refinement (pitch.c:511-512) needs when no shorter period wins.
     //   (xx, the chain at offset 0, came out of energy_sweeps)
+    // The neighbours of a shorter period T1(k) are fetched by a second, two-lane pass only when such a k wins.  (Round 2 ran
+    // all 30 neighbour chains speculatively on lanes 32..61: 59 lanes with unrelated offsets collide on the LDS banks --
+    // 2,860 LDS cycles per frame, half of them conflicts, a third of the whole kernel's; 31 lanes fill one 32-lane access
+    // group and leave the other empty.)
     {
       int off = -1;
       if (lane == 1) off = T0;
@@ -694,15 +765,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
         else T1b = (2 * sc[k] * T0 + k) / (2 * k);
         off = ((lane - 2) & 1) ? T1b : T1;
-      } else if (lane >= 32 && lane < 62) {
-        const int c = (lane - 32) >> 1;  // candidate 0: T0; candidate c >= 1: T1(k = c + 1)
-        const int Tc = c ? (2 * T0 + (c + 1)) / (2 * (c + 1)) : T0;
-        off = Tc + (((lane - 32) & 1) ? 1 : -1);
-        if (off < 0) off = 0;  // only for candidates the decision loop never selects (T1 < minperiod)
+      } else if (lane == 30 || lane == 31) {
+        off = T0 + ((lane & 1) ? 1 : -1);
+        if (off < 0) off = 0;
       }
       if (off >= 0) {
         const int a = maxperiod - off;  // y = x_lp + a
-        dots[lane] = chain_dot8_y2(x, (a & 1) ? xs + (a - 1) : xlp + a, N);
+        dots[lane] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
       }
     }
     RN_WSYNC();
@@ -755,7 +824,17 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     else pg = best_xy / (best_yy + 1);
     // 3-point refinement around the selected period: xcorr[k] = <x, x-(T+k-1)> (pitch.c:511-512)
     float xc1 = cand ? dots[2 + 2 * (cand - 1)] : dots[1];
-    float xc0 = dots[32 + 2 * cand], xc2 = dots[33 + 2 * cand];
+    float xc0 = dots[30], xc2 = dots[31];
+    if (cand) {  // (wave-uniform) a shorter period won: its two neighbours, T >= minperiod = 30 so both offsets are valid
+      RN_WSYNC();
+      if (lane < 2) {
+        const int a = maxperiod - (T + (lane ? 1 : -1));
+        dots[32 + lane] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
+      }
+      RN_WSYNC();
+      xc0 = dots[32];
+      xc2 = dots[33];
+    }
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS + 3] = T; dbg[RN_DBG_DOTS + 4] = xc0; dbg[RN_DBG_DOTS + 5] = xc1; dbg[RN_DBG_DOTS + 6] = xc2; }
     int off2 = 0;
     if ((xc2 - xc0) > .7f * (xc1 - xc0)) off2 = 1;

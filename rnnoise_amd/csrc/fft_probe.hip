@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) rn_fft_probe_kernel(const float *__restric
   __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))                                       \
   rn_fft_probe_occ##W##_kernel(const float *__restrict__ in, float *__restrict__ out, unsigned long long *__restrict__ clocks, \
                                int reps, RnTablesDev tb) {                                                              \
-    fft_probe_body<1>(in, out, clocks, reps, tb);                                                                       \
+    fft_probe_body<RN_FFT_XLANE>(in, out, clocks, reps, tb);                                                            \
   }
 OCC_KERNEL(4)
 OCC_KERNEL(5)
@@ -240,6 +240,7 @@ extern "C" hipError_t rn_launch_fft_probe(int variant, const float *in, float *o
   else if (variant == 15) hipLaunchKernelGGL(rn_fft_probe_occ5_kernel, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);
   else if (variant == 16) hipLaunchKernelGGL(rn_fft_probe_occ6_kernel, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);
   else if (variant == 18) hipLaunchKernelGGL(rn_fft_probe_occ8_kernel, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);
+  else if (variant == 3) hipLaunchKernelGGL(rn_fft_probe_kernel<2>, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);  // permlane32_swap form
   else if (variant == 0) hipLaunchKernelGGL(rn_fft_probe_kernel<0>, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);
   else hipLaunchKernelGGL(rn_fft_probe_kernel<1>, dim3(n), dim3(64), 0, st, in, out, clocks, reps, *tb);
   return hipGetLastError();

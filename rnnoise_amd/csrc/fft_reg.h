@@ -26,7 +26,8 @@
 #include <hip/hip_runtime.h>
 
 #ifndef RN_FFT_XLANE
-#define RN_FFT_XLANE 1  // 0: every exchange through ds_bpermute (reference implementation); 1: DPP / swizzle forms
+#define RN_FFT_XLANE 2  // 0: every exchange through ds_bpermute (reference implementation); 1: DPP / swizzle forms, lane ^ 32
+                        // through ds_bpermute; 2: as 1 with the lane ^ 32 level on v_permlane32_swap (no LDS)
 #endif
 
 struct rcpx { float r, i; };
@@ -57,7 +58,7 @@ __device__ __forceinline__ float xlane_xor(float v, int lane) {
     r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror:8
   } else if (MASK == 16) {
     r = __builtin_amdgcn_ds_swizzle(x, 0x401F);  // bit mode, xor_mask 16 (inside each half of the wave)
-  } else {
+  } else {  // MASK == 32 (variant 2 takes this level through v_permlane32_swap in fft_radix4_xlane and never gets here)
     r = __builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, x);
   }
   return __int_as_float(r);
@@ -80,8 +81,24 @@ __device__ __forceinline__ void fft_radix4_xlane(float (&ar)[15], float (&ai)[15
       xr = is0 ? xr : mr;
       xi = is0 ? xi : mi;
     }
-    const float tr = xlane_xor<(2 << SHIFT), VARIANT>(xr, lane) + fneg_if(xr, s1);
-    const float ti = xlane_xor<(2 << SHIFT), VARIANT>(xi, lane) + fneg_if(xi, s1);
+    float tr, ti;
+    if (VARIANT == 2 && SHIFT == 4) {
+      // level 1 of the last cross-lane stage, partner = lane ^ 32, without the LDS crossbar (ds_bpermute: 6 LDS cycles per
+      // value, profiles/r3_valu_issue.txt).  v_permlane32_swap exchanges the upper half of one register with the lower half
+      // of another: after swap(xr, xi) lanes 0..31 hold {xr[l], xr[l + 32]} and lanes 32..63 {xi[l - 32], xi[l]}, so every
+      // lane forms BOTH results of its pair -- partner + own for the lower lane (roles 0, 1), partner + (-own) = a - b for the
+      // upper one (roles 2, 3; same operands, same rounding) -- and a second swap puts them where the butterfly wants them.
+      typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+      const v2u_ sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr), __float_as_uint(xi), false, false);
+      const float lo = __uint_as_float(sw.x), hi = __uint_as_float(sw.y);   // lo = the pair's lower-lane value, hi = its upper-lane value
+      const float sum = hi + lo, dif = lo - hi;
+      const v2u_ sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(dif), false, false);
+      tr = __uint_as_float(sw2.x);
+      ti = __uint_as_float(sw2.y);
+    } else {
+      tr = xlane_xor<(2 << SHIFT), VARIANT>(xr, lane) + fneg_if(xr, s1);
+      ti = xlane_xor<(2 << SHIFT), VARIANT>(xi, lane) + fneg_if(xi, s1);
+    }
     const float wr = is3 ? ti : tr;
     const float wi = is3 ? fneg_if(tr, 0x80000000u) : ti;
     ar[b] = xlane_xor<(1 << SHIFT), VARIANT>(wr, lane) + fneg_if(wr, s2);

@@ -79,11 +79,12 @@ def test_16384_streams_on_the_host_profile(blob_default):
     _tiled_check(blob_default, 16384, (3, 4), silent_stream=5)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 def test_register_fft_bit_exact(variant):
     """F1 in isolation: the register-resident 960-point transform of the analysis / synthesis kernels (fft_reg.h; reference
     rnn_fft_c, src/kiss_fft.c:518-586) against the oracle's FFT on random, impulse, DC, alternating, tiny (denormal products)
-    and huge inputs.  variant 0 = every exchange through ds_bpermute, 1 = the DPP / swizzle forms the kernels use."""
+    and huge inputs.  variant 0 = every exchange through ds_bpermute, 1 = DPP / swizzle forms, 3 = what the kernels use: as 1 with the
+    lane ^ 32 level on v_permlane32_swap."""
     import ctypes as C
     rng = np.random.default_rng(960 + variant)
     cases = [(rng.standard_normal((960, 2)) * 3000).astype(np.float32) for _ in range(6)]
