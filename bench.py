@@ -7,7 +7,7 @@ stream of the batch advances by one 480-sample frame (high-pass -> analysis -> n
 synthesis).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--model default|little]
-                  [--nn mfma|vector] [--repeats R] [--host-io]
+                  [--nn mfma|vector] [--repeats R] [--host-io] [--s16] [--frames-per-call F]
 
 Workload at N=1: BASELINE.json configs[2] -- 65,536 concurrent streams on one MI355X (the largest
 single-GPU configuration), default architecture, int8 model, network recast as batched MFMA
@@ -67,7 +67,9 @@ ALG_BYTES = {
 }
 KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "network": "rn_nn_mfma_kernel",
              "synthesis": "rn_synthesis_kernel"}
-NN_LAYERS_MIN_STREAMS = 16384  # shim.cpp nn_layers_min_streams(): from here up the network runs as five launches
+# shim.cpp nn_layers_min_streams(): from here up the network runs as five launches (the library honours the same variable)
+NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "16384"))
+N_CU = 256
 NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
 
 
@@ -90,9 +92,26 @@ def waves_per_launch(kind: str, n_streams: int) -> int:
             "synthesis": n_streams}[kind]
 
 
+def valu_cost(kernel: str) -> float:
+    """Mean clocks per wave64 VALU instruction per SIMD of `kernel`: its instruction mix (tools/valu_mix.py over the built
+    objects -> profiles/valu_mix.json) priced with the per-instruction issue costs MEASURED on the MI355X
+    (profiles/r3_valu_issue.txt: 2.26 clk for plain f32/u32 VOP2 forms, 4.15 for DPP / SGPR-source / packed / f64 / compare /
+    select / convert / 3-operand forms, 8.12 for transcendentals and v_permlane32_swap).  MI355X_MICROARCH.md's "2 cycles per
+    wave64 v_fma_f32" holds for the first class only; the PMC ratio 4*SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU (4.0 for every
+    kernel) is a property of the counter.  4.15 when the kernel has no record."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
+            return float(json.load(f)["kernels"][kernel]["mean_cycles"])
+    except Exception:
+        return 4.15
+
+
+VALU_FLOOR = 2.26  # clocks per wave64 instruction if every one were a plain f32 VOP2 (the guide's vector-f32 peak, as measured)
+
+
 def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma"):
     """VALU issue time of one frame step if every SIMD issued back to back: over the step's kernels, waves x VALU instructions
-    per wave x the measured clocks per instruction (profiles/pmc_by_streams.json), spread over 1024 SIMDs at 2.4 GHz.
+    per wave (PMC, profiles/pmc_by_streams.json) x valu_cost(kernel), spread over 1024 SIMDs at 2.4 GHz.
     None when a kernel of the step has no PMC record (the vector network path)."""
     n = n_streams
     launches = [("rn_hp_kernel", -(-n // 64)), (kernel_of("analysis", n, nn), n), ("rn_synthesis_kernel", n)]
@@ -107,7 +126,7 @@ def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma")
         r = pmc_record(kernel, n, model)
         if not r or "valu_per_wave" not in r:
             return None
-        cycles += waves * r["valu_per_wave"] * r.get("valu_cycles_per_inst", 4)
+        cycles += waves * r["valu_per_wave"] * valu_cost(r.get("kernel", kernel))
     return 1e3 * cycles / N_SIMD / CLOCK_HZ
 
 
@@ -223,6 +242,48 @@ def cpu_baseline(blob: bytes):
     return None
 
 
+def parity_leg(capi, torch, batch, blob, d_in, n_frames: int, s16: bool):
+    """Checker leg (SURVEY 8d "parity summary of the same run"), outside the timed region: the batch that was just timed
+    is reset and fed the first `n_frames` frames of the bench's own input in ONE call (default schedule, the pipelined
+    route the timed region took); 16 streams from the start and 16 from the end of the batch are compared bit for bit --
+    PCM, VAD, raw gains -- with the oracle (oracle/, the CPU restatement pinned to the compiled reference) run on the same
+    samples under the rcpps profile the library is using."""
+    import numpy as np
+    from oracle import binding
+    N = batch.n
+    prof = capi.rcp_profile()
+    binding.set_rcp_profile("host" if prof.startswith("host") else prof)
+    sample = list(range(min(16, N))) + list(range(max(16, N - 16), N) if N > 16 else [])
+    x = d_in[:n_frames]
+    dev = x.device
+    out = torch.empty_like(x, dtype=torch.int16 if s16 else torch.float32)
+    xin = x.to(torch.int16) if s16 else x.contiguous()
+    vad = torch.empty((n_frames, N), device=dev)
+    gains = torch.empty((n_frames, N, 32), device=dev)
+    batch.reset()
+    batch.process_device(out.data_ptr(), xin.data_ptr(), vad.data_ptr(), gains.data_ptr(), n_frames,
+                         torch.cuda.current_stream().cuda_stream, s16=s16)
+    torch.cuda.synchronize()
+    idx = torch.tensor(sample, device=dev)
+    got_o, got_v, got_g = out[:, idx].cpu().numpy(), vad[:, idx].cpu().numpy(), gains[:, idx].cpu().numpy()
+    pcm = x[:, idx].cpu().numpy()
+    bad = 0
+    for j in range(len(sample)):
+        want = binding.Oracle(blob).run(pcm[:, j])
+        wo = want["out"]
+        if s16:  # examples/rnnoise_demo.c:58, x86 conversion: cvttss2si, low 16 bits
+            wi = np.where((wo >= -2147483648.0) & (wo < 2147483648.0), np.trunc(wo), -2147483648.0).astype(np.int64)
+            same_o = np.array_equal(got_o[:, j], (wi & 0xFFFF).astype(np.uint16).view(np.int16))
+        else:
+            same_o = np.array_equal(got_o[:, j].view(np.uint32), wo.view(np.uint32))
+        if not (same_o and np.array_equal(got_v[:, j].view(np.uint32), want["vad"].view(np.uint32))
+                and np.array_equal(got_g[:, j].view(np.uint32), want["gains"].view(np.uint32))):
+            bad += 1
+    return {"streams": len(sample), "frames": n_frames, "bit_identical": bad == 0, "streams_differing": bad,
+            "batch_streams": N, "checked": "pcm" + (" (s16)" if s16 else "") + ", vad, raw gains", "rcp_profile": prof,
+            "against": "oracle/rn_oracle.c (pinned to the compiled reference)"}
+
+
 class StubBatch:
     """Launcher self-test only (--stub, CPU + gloo; tests/test_bench_launcher_cpu.py): stands in for capi.Batch so that
     the rank / shard / aggregate / rank-0-JSON logic of THIS file can run where no GPU exists.  It computes nothing; the
@@ -267,7 +328,8 @@ def workload_name(a, n_streams: int) -> str:
     dens = "density 1/3" if a.model == "default" else "sparser blob (rnnoise_data_little stand-in)"
     return (f"BASELINE {cfg}: {n_streams} concurrent streams per GPU, default architecture (conv 65x3->128->384, "
             f"3xGRU(384) block-sparse int8, {dens}), synthetic exporter-made model, network path = {a.nn}"
-            + (", host-fed (pinned, double-buffered PCIe)" if a.host_io else ""))
+            + (", host-fed (pinned, double-buffered PCIe)" if a.host_io else "") + (", int16 PCM at both ends" if a.s16 else "")
+            + (f", {a.frames_per_call} frame(s) per call" if a.frames_per_call else ""))
 
 
 def bench_rank(a) -> dict | None:
@@ -323,7 +385,9 @@ def bench_rank(a) -> dict | None:
         cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))
         if a.host_io:
             cap = max(4, min(cap, (1 << 30) // (N * FRAME * 4)))  # pinned host memory: 1 GB each way at most
-        d_in = synth_pcm_torch(torch, N, cap, dev, seed_base=mine.start)
+        d_in = d_in_f32 = synth_pcm_torch(torch, N, cap, dev, seed_base=mine.start)
+        if a.s16:
+            d_in = d_in.to(torch.int16)  # (the synthetic samples are s16-rounded already: exact)
         d_out = torch.empty_like(d_in)
         d_vad = torch.empty((cap, N), device=dev)
         d_gains = torch.empty((cap, N, 32), device=dev)
@@ -332,20 +396,20 @@ def bench_rank(a) -> dict | None:
             h_in = d_in.cpu().pin_memory()
             h_out = torch.empty_like(h_in).pin_memory()
             h_vad = torch.empty((cap, N)).pin_memory()
-    esz = N * FRAME * 4
+    esz = N * FRAME * (2 if a.s16 else 4)
 
     def run(first: int, count: int):
         f, left = first, count
         while left > 0:
             k = f % cap
-            n = min(left, cap - k)
+            n = min(left, cap - k, a.frames_per_call or left)
             if stub:
                 batch.process_device()
             elif a.host_io:
-                batch.process_into(h_out.data_ptr() + k * esz, h_in.data_ptr() + k * esz, h_vad.data_ptr() + k * N * 4, 0, n)
+                batch.process_into(h_out.data_ptr() + k * esz, h_in.data_ptr() + k * esz, h_vad.data_ptr() + k * N * 4, 0, n, s16=a.s16)
             else:
                 batch.process_device(d_out.data_ptr() + k * esz, d_in.data_ptr() + k * esz, d_vad.data_ptr() + k * N * 4,
-                                     d_gains.data_ptr() + k * N * 128, n, stream)
+                                     d_gains.data_ptr() + k * N * 128, n, stream, s16=a.s16)
             f += n
             left -= n
 
@@ -388,7 +452,11 @@ def bench_rank(a) -> dict | None:
         n_launch = {k: (len(NN_LAYER_KERNELS) if k == "network" and a.nn == "mfma" and N >= NN_LAYERS_MIN_STREAMS else 1) for k in kinds}
         dom = max(kinds, key=lambda k: kms[k] / n_launch[k])
         kname = kernel_of(dom, N, a.nn)
-        ach = per_launch[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        # a kind of several launches (the layer-wise network) is represented by its MEAN launch: a fifth of the kind's bytes in a
+        # fifth of the kind's time (the library times the five launches separately but reports their sum)
+        dom_ms = kms[dom] / n_launch[dom]
+        dom_bytes = per_launch[dom] // n_launch[dom]
+        ach = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         pmc = pmc_record(kname, N, a.model) or {}
         traffic = int(pmc["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pmc else None
         line = {
@@ -404,12 +472,12 @@ def bench_rank(a) -> dict | None:
                        "stream_ids_rank0": [mine.start, mine.stop]},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch[dom],
+                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": round(dom_ms, 4),
                          "kernel_ms": {k: round(kms[k], 4) for k in kinds},
                          "launches_per_step": n_launch,
                          "note": "dominant kernel = longest single launch by HIP-event time inside the timed region (kernel_ms adds up "
                                  "the launches of a kind; overlapping kernels of neighbouring frames stretch each other's durations); "
-                                 "it is issue/latency-bound, not HBM-bound: see roofline_valu"},
+                                 "it is LDS/issue-bound, not HBM-bound: see roofline_lds and roofline_valu"},
             # whole step against HBM: mandatory bytes of all four kernels / step time
             "roofline_step": {"bound": "hbm", "achieved": round(sum(per_launch.values()) / (med / K) / 1e9, 2),
                               "unit": "GB/s", "frac": round(sum(per_launch.values()) / (med / K) / HBM_PEAK, 5),
@@ -422,38 +490,64 @@ def bench_rank(a) -> dict | None:
             da = max(kinds, key=lambda k: kms_alone[k] / n_launch[k])
             na = kernel_of(da, N, a.nn)
             pa = pmc_record(na, N, a.model) or {}
-            aa = per_launch[da] / (kms_alone[da] * 1e-3) / 1e9
+            da_ms, da_bytes = kms_alone[da] / n_launch[da], per_launch[da] // n_launch[da]
+            aa = da_bytes / (da_ms * 1e-3) / 1e9
             line["roofline_standalone"] = {
                 "bound": "hbm", "kernel": na, "achieved": round(aa, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(aa * 1e9 / HBM_PEAK, 5),
                 "traffic": int(pa["hbm_bytes_per_frame"] * N) if "hbm_bytes_per_frame" in pa else None,
-                "algorithmic_bytes_per_launch": per_launch[da], "kernel_ms": {k: round(kms_alone[k], 4) for k in kinds},
+                "algorithmic_bytes_per_launch": da_bytes, "launch_ms": round(da_ms, 4),
+                "kernel_ms": {k: round(kms_alone[k], 4) for k in kinds},
                 "note": "same workload, every kernel on one stream (no overlap between kernels), outside the timed region"}
+            wa = waves_per_launch(da, N)  # (of ONE launch, also for the layer-wise network)
             if "valu_per_wave" in pa:
-                ti = pa["valu_per_wave"] * waves_per_launch(da, N) * pa.get("valu_cycles_per_inst", 4) / N_SIMD / CLOCK_HZ
-                line["roofline_standalone"]["valu_issue_frac"] = round(ti / (kms_alone[da] * 1e-3), 4)
-                line["roofline_standalone"]["valu_note"] = (f"{pa['valu_per_wave']} VALU instructions per wave x "
-                                                           f"{pa.get('valu_cycles_per_inst', 4)} clk (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, measured) "
+                ti = pa["valu_per_wave"] * wa * valu_cost(pa.get("kernel", na)) / N_SIMD / CLOCK_HZ
+                line["roofline_standalone"]["valu_issue_frac"] = round(ti / (da_ms * 1e-3), 4)
+                line["roofline_standalone"]["valu_note"] = (f"{pa['valu_per_wave']} VALU instructions per wave (PMC) x "
+                                                           f"{valu_cost(pa.get('kernel', na)):.2f} clk (instruction mix priced with profiles/r3_valu_issue.txt) "
                                                            "over 1024 SIMDs at 2.4 GHz")
-        if "valu_per_wave" in pmc and kms[dom] > 0:
-            # VALU-issue bound: instructions x the measured issue cost (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU ~ 4 clk per wave64
-            # instruction on this kernel mix, not the 2 clk of a pure f32 stream) spread over 1024 SIMDs at 2.4 GHz
-            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * pmc.get("valu_cycles_per_inst", 4) / N_SIMD / CLOCK_HZ
+            if "lds_cycles_per_wave" in pa:
+                tl = pa["lds_cycles_per_wave"] * wa / N_CU / CLOCK_HZ
+                line["roofline_standalone"]["lds_port_frac"] = round(tl / (da_ms * 1e-3), 4)
+        if "valu_per_wave" in pmc and dom_ms > 0:
+            # VALU-issue bound of the dominant launch: instructions per wave (PMC) x the mean issue cost of this kernel's
+            # instruction mix (valu_cost) x waves, spread over 1024 SIMDs at 2.4 GHz.  frac_f32_peak prices every instruction
+            # at the plain-f32 rate instead (the guide's vector peak): a floor no mix with DPP / f64 / selects can reach.
+            cpi = valu_cost(pmc.get("kernel", kname))
+            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * cpi / N_SIMD / CLOCK_HZ
             line["roofline_valu"] = {"bound": "valu-issue", "kernel": kname, "valu_insts_per_wave": pmc["valu_per_wave"],
-                                     "waves": waves_per_launch(dom, N), "issue_bound_ms": round(1e3 * t_issue, 4),
-                                     "frac": round(t_issue / (kms[dom] * 1e-3), 4), "source": pmc.get("source", "profiles/")}
+                                     "waves": waves_per_launch(dom, N), "clocks_per_inst": cpi, "issue_bound_ms": round(1e3 * t_issue, 4),
+                                     "frac": round(t_issue / (dom_ms * 1e-3), 4),
+                                     "frac_f32_peak": round(t_issue * VALU_FLOOR / cpi / (dom_ms * 1e-3), 4),
+                                     "peak": "1024 SIMDs x 2.4 GHz / clocks_per_inst wave64 instructions/s; clocks_per_inst = this kernel's "
+                                             "instruction mix priced with the per-instruction costs measured in profiles/r3_valu_issue.txt "
+                                             "(frac_f32_peak: every instruction at 2.26 clk, the measured plain-f32 rate)",
+                                     "source": pmc.get("source", "profiles/")}
+        if "lds_cycles_per_wave" in pmc and dom_ms > 0:
+            # LDS-port bound: SQ_LDS_IDX_ACTIVE cycles per wave (PMC: cycles the CU's one LDS pipe is busy for this wave,
+            # bank-conflict replays included) x waves / 256 CUs / 2.4 GHz
+            t_lds = pmc["lds_cycles_per_wave"] * waves_per_launch(dom, N) / N_CU / CLOCK_HZ
+            line["roofline_lds"] = {"bound": "lds-port", "kernel": kname, "lds_cycles_per_wave": pmc["lds_cycles_per_wave"],
+                                    "waves": waves_per_launch(dom, N), "port_bound_ms": round(1e3 * t_lds, 4),
+                                    "frac": round(t_lds / (dom_ms * 1e-3), 4),
+                                    "peak": "one LDS pipe per CU: 256 CUs x 2.4 GHz port-cycles/s", "source": pmc.get("source", "profiles/")}
         try:  # the whole step against VALU issue: every kernel of it is issue-bound to first order
             vi = step_valu_issue_ms(N, a.model, a.nn)
             if vi and med > 0:
                 line["roofline_step_valu"] = {"bound": "valu-issue", "issue_bound_ms": round(vi, 4),
                                               "frac": round(vi / (1e3 * med / K), 4),
-                                              "definition": "sum over the step's kernels of waves x VALU instructions per wave x measured "
-                                                            "clocks per instruction (PMC passes under profiles/), over 1024 SIMDs at 2.4 GHz, "
-                                                            "divided by ms_per_step"}
+                                              "definition": "sum over the step's kernels of waves x VALU instructions per wave (PMC passes under "
+                                                            "profiles/) x that kernel's mix-priced clocks per instruction (profiles/valu_mix.json, "
+                                                            "profiles/r3_valu_issue.txt), over 1024 SIMDs at 2.4 GHz, divided by ms_per_step"}
         except Exception:
             pass
         if stub:
             line["stub"] = True
+        if not stub and not a.no_parity:
+            try:
+                line["parity"] = parity_leg(capi, torch, batch, blob, d_in_f32, min(cap, 12), a.s16)
+            except Exception as e:  # the checker failing to run is reported, never hidden
+                line["parity"] = {"bit_identical": None, "error": repr(e)[:300]}
         if world == 1 and not a.no_cpu_baseline and not stub:
             cb = cpu_baseline(blob)
             if cb:
@@ -475,7 +569,11 @@ def parse_args(argv=None):
     ap.add_argument("--nn", choices=["vector", "mfma"], default=os.environ.get("RNNOISE_AMD_NN", "mfma"),
                     help="network path: batched MFMA (default) or the v_dot4 vector path; identical bits")
     ap.add_argument("--host-io", action="store_true", help="feed host buffers through rnnoise_batch_process (PCIe-inclusive)")
+    ap.add_argument("--s16", action="store_true", help="int16 PCM at both ends (rnnoise_batch_process[_device]_s16)")
+    ap.add_argument("--frames-per-call", type=int, default=0,
+                    help="frames per library call (0 = as many as the step count allows; 1 = the cadence of a real-time server)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher self-test on CPU (gloo)
     return ap.parse_args(argv)
 

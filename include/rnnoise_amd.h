@@ -63,6 +63,16 @@ RNNOISE_EXPORT int rnnoise_batch_process(RNNoiseBatch *b, float *out, const floa
 RNNOISE_EXPORT int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
                                                 float *d_gains, int n_frames, void *hip_stream);
 
+/* The same two calls with 16-bit PCM at both ends: in / out : [n_frames][n_streams][480] int16.  The conversions are those
+ * of the reference's only caller (examples/rnnoise_demo.c:56,58: x[i] = tmp[i] going in, tmp[i] = x[i] -- the C float -> short
+ * conversion as x86 compiles it, truncation toward zero -- coming out) done inside the first and the last kernel of the step,
+ * so a frame moves 2 x 960 bytes instead of 2 x 1,920 over HBM and PCIe.  Bits are those of the float calls followed by
+ * that cast.  Device buffers 8-byte aligned.  The float and s16 calls may be mixed on one batch. */
+RNNOISE_EXPORT int rnnoise_batch_process_s16(RNNoiseBatch *b, short *out, const short *in, float *vad, float *gains,
+                                             int n_frames);
+RNNOISE_EXPORT int rnnoise_batch_process_device_s16(RNNoiseBatch *b, short *d_out, const short *d_in, float *d_vad,
+                                                    float *d_gains, int n_frames, void *hip_stream);
+
 /* Portable per-stream state: RN_STATE_FLOATS 32-bit words laid out as in rn_layout.h
  * (the 25,128 live bytes of the reference's DenoiseState).  Import requires
  * analysis_mem == the last 480 samples of pitch_buf, which every state produced by the

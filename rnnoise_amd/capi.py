@@ -33,6 +33,7 @@ EXPORTS = [
     "rnnoise_model_from_filename", "rnnoise_model_free",
     "rnnoise_amd_device_count", "rnnoise_batch_create", "rnnoise_batch_destroy", "rnnoise_batch_size",
     "rnnoise_batch_reset", "rnnoise_batch_process", "rnnoise_batch_process_device",
+    "rnnoise_batch_process_s16", "rnnoise_batch_process_device_s16",
     "rnnoise_batch_export_state", "rnnoise_batch_import_state", "rnnoise_batch_set_nn_path",
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms",
@@ -120,6 +121,8 @@ def _load(path, debug):
         L.rnnoise_batch_reset.argtypes = [vp]
         L.rnnoise_batch_process.argtypes = [vp, fp, fp, fp, fp, C.c_int]
         L.rnnoise_batch_process_device.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+        L.rnnoise_batch_process_s16.argtypes = [vp, C.POINTER(C.c_short), C.POINTER(C.c_short), fp, fp, C.c_int]
+        L.rnnoise_batch_process_device_s16.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
         L.rnnoise_batch_export_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_import_state.argtypes = [vp, C.c_int, fp]
         L.rnnoise_batch_set_nn_path.argtypes = [vp, C.c_int]
@@ -249,18 +252,33 @@ class Batch:
             raise RuntimeError("rnnoise_batch_process failed")
         return out, vad, gains
 
-    def process_into(self, out_ptr: int, in_ptr: int, vad_ptr: int, gains_ptr: int, n_frames: int):
-        """rnnoise_batch_process on raw HOST pointers (ints).  Pinned memory (hipHostMalloc / torch pin_memory) is read
+    def process_s16(self, pcm: np.ndarray, want_gains: bool = True):
+        """pcm: (T, N, 480) int16 host array -> (out int16, vad[T,N], gains[T,N,32]): rnnoise_batch_process_s16, the
+        conversions of examples/rnnoise_demo.c:56,58 done on the device."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        T, N, F = pcm.shape
+        assert N == self.n and F == FRAME
+        out = np.empty_like(pcm)
+        vad = np.empty((T, N), np.float32)
+        gains = np.empty((T, N, NB_BANDS), np.float32) if want_gains else None
+        sp = C.POINTER(C.c_short)
+        if lib().rnnoise_batch_process_s16(self.h, out.ctypes.data_as(sp), pcm.ctypes.data_as(sp), _fp(vad), _fp(gains), T):
+            raise RuntimeError("rnnoise_batch_process_s16 failed")
+        return out, vad, gains
+
+    def process_into(self, out_ptr: int, in_ptr: int, vad_ptr: int, gains_ptr: int, n_frames: int, s16: bool = False):
+        """rnnoise_batch_process[_s16] on raw HOST pointers (ints).  Pinned memory (hipHostMalloc / torch pin_memory) is read
         and written by DMA in place; pageable memory goes through the library's pinned bounce buffers."""
         fp = C.POINTER(C.c_float)
-        if lib().rnnoise_batch_process(self.h, C.cast(out_ptr, fp), C.cast(in_ptr, fp), C.cast(vad_ptr or None, fp),
-                                       C.cast(gains_ptr or None, fp), n_frames):
+        pp = C.POINTER(C.c_short) if s16 else fp
+        fn = lib().rnnoise_batch_process_s16 if s16 else lib().rnnoise_batch_process
+        if fn(self.h, C.cast(out_ptr, pp), C.cast(in_ptr, pp), C.cast(vad_ptr or None, fp), C.cast(gains_ptr or None, fp), n_frames):
             raise RuntimeError("rnnoise_batch_process failed")
 
-    def process_device(self, d_out: int, d_in: int, d_vad: int, d_gains: int, n_frames: int, stream: int = 0):
-        """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle)."""
-        if lib().rnnoise_batch_process_device(self.h, d_out, d_in, d_vad or None, d_gains or None, n_frames,
-                                              stream or None):
+    def process_device(self, d_out: int, d_in: int, d_vad: int, d_gains: int, n_frames: int, stream: int = 0, s16: bool = False):
+        """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle); s16: the PCM buffers hold int16."""
+        fn = lib().rnnoise_batch_process_device_s16 if s16 else lib().rnnoise_batch_process_device
+        if fn(self.h, d_out, d_in, d_vad or None, d_gains or None, n_frames, stream or None):
             raise RuntimeError("rnnoise_batch_process_device failed")
 
     def export_state(self, stream: int) -> np.ndarray:

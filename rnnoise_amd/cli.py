@@ -3,7 +3,8 @@ files out, one GPU batch.
 
 Per file the semantics are those of the reference's examples/rnnoise_demo.c:52-61: samples are
 fed unscaled (+-32768 range), the first output frame is dropped, the float result is cast to
-short by truncation, a trailing partial frame is ignored.  Files of different lengths share the
+short by truncation, a trailing partial frame is ignored.  The samples cross PCIe as int16 both
+ways (rnnoise_batch_process_s16: the two conversions of rnnoise_demo.c:56,58 run on the device).  Files of different lengths share the
 batch; a stream whose file has ended is fed zeros and produces no more output.
 
   python -m rnnoise_amd.cli denoise --model weights_blob.bin --out-dir out  a.raw b.raw ...
@@ -33,7 +34,7 @@ def denoise_files(model_blob: bytes, inputs, out_dir: str, chunk_frames: int = 1
     ins = [open(p, "rb") for p in inputs]
     outs = [open(os.path.join(out_dir, os.path.basename(p) + ".denoised.raw"), "wb") for p in inputs]
     vfs = [open(os.path.join(out_dir, os.path.basename(p) + ".vad.csv"), "w") for p in inputs] if vad_csv else None
-    buf = np.zeros((min(chunk_frames, max(T, 1)), N, FRAME), np.float32)
+    buf = np.zeros((min(chunk_frames, max(T, 1)), N, FRAME), np.int16)
     for t0 in range(0, T, chunk_frames):
         tn = min(chunk_frames, T - t0)
         chunk = buf[:tn]
@@ -43,12 +44,12 @@ def denoise_files(model_blob: bytes, inputs, out_dir: str, chunk_frames: int = 1
             if k:
                 x = np.frombuffer(f.read(k * FRAME * 2), dtype=np.int16)
                 chunk[:k, s] = x.reshape(k, FRAME)
-        out, vad, _ = batch.process(chunk, want_gains=False)
+        out, vad, _ = batch.process_s16(chunk, want_gains=False)
         for s in range(N):
             k = max(0, min(tn, n_frames[s] - t0))
             first = 1 if t0 == 0 else 0  # the demo drops the first output frame (rnnoise_demo.c:59-60)
             if k > first:
-                outs[s].write(out[first:k, s].astype(np.int16).tobytes())  # C (short) cast: truncation
+                outs[s].write(out[first:k, s].tobytes())  # (the demo's truncating (short) cast was done on the device)
             if vfs and k:
                 vfs[s].write("".join(f"{v:.6f}\n" for v in vad[:k, s]))
     for f in ins + outs + (vfs or []):

@@ -1037,7 +1037,12 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052, "synthesis LDS
 // samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity, int prev) {
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev) {
+  // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
+  // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
+  // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
+  const int parity = parity_arg & 255;
+  const bool out_s16 = parity_arg & 256;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
   const int s = blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
@@ -1170,8 +1175,17 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
     float v = (float)RN_WINDOW_SIZE * yr[b];
     v *= wv[b];
-    if (lo) o[n] = v + smv[b];
-    else sm[RN_FRAME_SIZE - p] = v;
+    if (lo) {
+      const float r = v + smv[b];
+      if (out_s16) {
+        const int q = (r >= -2147483648.f && r < 2147483648.f) ? (int)r : (int)0x80000000;
+        reinterpret_cast<short *>(out)[(size_t)s * RN_FRAME_SIZE + n] = (short)q;
+      } else {
+        o[n] = r;
+      }
+    } else {
+      sm[RN_FRAME_SIZE - p] = v;
+    }
   }
 }
 
@@ -1204,8 +1218,9 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
                      slot, parity, *tr);
   return hipGetLastError();
 }
-extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, float *out, int cur, int prev,
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, void *out, int out_s16, int cur, int prev,
                                           hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, out, cur, prev);
+  RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, static_cast<float *>(out),
+            cur | (out_s16 ? 256 : 0), prev);
   return hipGetLastError();
 }

@@ -18,7 +18,10 @@
 // fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp) {
+rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
+  // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
+  // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
+  const int apply_hp = mode & 1, in_s16 = mode & 2;
   const int s = blockIdx.x * WAVE + threadIdx.x;
   if (s >= g.n_streams) return;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
@@ -30,14 +33,22 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
   // filtered: with one wave per SIMD nothing else hides the HBM round trip
   constexpr int BLK = 8;  // float4 per block
   float4 cur[BLK], nxt[BLK];
+  const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
+  auto load4 = [&](int idx) -> float4 {
+    if (in_s16) {
+      const short4 q = x16[idx];
+      return make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+    }
+    return x[idx];
+  };
 #pragma unroll
-  for (int j = 0; j < BLK; j++) nxt[j] = x[j];
+  for (int j = 0; j < BLK; j++) nxt[j] = load4(j);
   for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
 #pragma unroll
     for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
     if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
 #pragma unroll
-      for (int j = 0; j < BLK; j++) nxt[j] = x[(blk + 1) * BLK + j];
+      for (int j = 0; j < BLK; j++) nxt[j] = load4((blk + 1) * BLK + j);
     }
 #define HP_STEP(xi, yo)                                              \
     {                                                                \
@@ -171,8 +182,9 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int apply_hp)
 }
 
 
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const float *in, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
-  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, in, slot, 1);
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
+  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot,
+            1 | (in_s16 ? 2 : 0));
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {

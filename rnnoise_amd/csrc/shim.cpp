@@ -25,10 +25,10 @@
 #endif
 #include "rcp_profiles.h"
 
-extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const float *, int, hipStream_t, hipEvent_t, hipEvent_t);
+extern "C" hipError_t rn_launch_hp(const RnGroupDev *, const void *, int in_s16, int, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_analysis(const RnGroupDev *, const RnTablesDev *, int, int, hipStream_t, hipEvent_t, hipEvent_t);
-extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, float *, int, int, hipStream_t, hipEvent_t,
-                                          hipEvent_t);
+extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *, const RnTablesDev *, void *, int out_s16, int, int, hipStream_t,
+                                          hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_train_features(const RnGroupDev *, const RnTablesDev *, const float *, int, int,
                                                const RnTrainArgs *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
@@ -569,6 +569,7 @@ struct RNNoiseBatch {
     float *d_in[2] = {}, *d_out[2] = {}, *d_vad[2] = {}, *d_gains[2] = {};
     float *h_in[2] = {}, *h_out[2] = {}, *h_vad[2] = {}, *h_gains[2] = {};
     int chunk_frames = 0;
+    size_t pcm_floats = 0;  // capacity of d_in / d_out (and h_in / h_out) of one chunk
   } io;
   // timing
   bool timing = false;
@@ -1016,12 +1017,16 @@ extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
   return old;
 }
 
-extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
-                                            float *d_gains, int n_frames, void *hip_stream) {
-  if (!b || !d_out || !d_in || n_frames < 0) return -1;
+// PCM frames are float (the reference API's sample type) or, with s16 set, int16 converted at the two ends of the step as the
+// reference's only caller does (examples/rnnoise_demo.c:56,58): half the bytes over HBM and, in the host-fed path, PCIe.
+static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v, float *d_vad, float *d_gains,
+                                     int n_frames, void *hip_stream, bool s16) {
+  if (!b || !d_out_v || !d_in_v || n_frames < 0) return -1;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   ON_DEVICE(b->device);
-  const size_t N = b->n;
+  const size_t N = b->n, esz = s16 ? sizeof(short) : sizeof(float);
+  const char *d_in = static_cast<const char *>(d_in_v);
+  char *d_out = static_cast<char *>(d_out_v);
   // Multi-frame calls are software-pipelined over three streams: C runs the high-pass of frames up to
   // f+2, B the analysis of frame f+1, A (the caller's stream) network + synthesis of frame f.
   // What makes that legal:
@@ -1079,7 +1084,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     if (side_k1 && f >= 4 && !hp_early) HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[(f - 4) & 7], 0));
     TimedLaunch t(b, 3);
     b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
-    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
+    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE * esz, s16, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
                         b->cur_hp[f & 7]));
     return 0;
   };
@@ -1133,7 +1138,7 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
     {
       TimedLaunch t(b, 2);
       b->cur_k3[f & 7] = t.on ? t.stop() : (side_k1 ? b->own_k3[f & 7] : nullptr);
-      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE, cur, prev, st, t.start(), b->cur_k3[f & 7]));
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE * esz, s16, cur, prev, st, t.start(), b->cur_k3[f & 7]));
     }
     b->launches += b->timing ? 1 : 0;
   }
@@ -1141,6 +1146,16 @@ extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const
   b->ring_slot = (b->ring_slot + n_frames) % RN_RING_SLOTS;
   b->frame_no += n_frames;
   return 0;
+}
+
+extern "C" int rnnoise_batch_process_device(RNNoiseBatch *b, float *d_out, const float *d_in, float *d_vad,
+                                            float *d_gains, int n_frames, void *hip_stream) {
+  return batch_process_device_impl(b, d_out, d_in, d_vad, d_gains, n_frames, hip_stream, false);
+}
+
+extern "C" int rnnoise_batch_process_device_s16(RNNoiseBatch *b, short *d_out, const short *d_in, float *d_vad,
+                                                float *d_gains, int n_frames, void *hip_stream) {
+  return batch_process_device_impl(b, d_out, d_in, d_vad, d_gains, n_frames, hip_stream, true);
 }
 
 // ---- host-fed path (pinned, double-buffered H2D / D2H) ----
@@ -1168,12 +1183,16 @@ static void host_io_release(RNNoiseBatch *b) {
 
 // device (and, for pageable callers, pinned host) staging for two chunks of `frames` frames each: one allocation per
 // side and chunk, carved into in | out | vad | gains
-static int host_io_prepare(RNNoiseBatch *b, int frames, bool bounce) {
+static int host_io_prepare(RNNoiseBatch *b, int frames, size_t esz, bool bounce) {
   RNNoiseBatch::HostIo &io = b->io;
-  if (io.chunk_frames >= frames && (!bounce || io.h_in[0])) return 0;
+  const size_t N = b->n;
+  size_t n_in = ((size_t)frames * N * RN_FRAME_SIZE * esz + 255) / 256 * 64;  // floats' worth of PCM per chunk and direction
+  if (io.chunk_frames >= frames && io.pcm_floats >= n_in && (!bounce || io.h_in[0])) return 0;
   const bool had_bounce = io.h_in[0] != nullptr;
+  frames = std::max(frames, io.chunk_frames);  // (float and s16 callers alternating on one batch: grow once, to both)
+  n_in = std::max(n_in, io.pcm_floats);
   host_io_release(b);
-  const size_t N = b->n, fr = (size_t)frames, n_in = fr * N * RN_FRAME_SIZE, n_vad = fr * N, n_g = fr * N * RN_NB_BANDS;
+  const size_t fr = (size_t)frames, n_vad = fr * N, n_g = fr * N * RN_NB_BANDS;
   const size_t total = (2 * n_in + n_vad + n_g) * sizeof(float);
   HIP_OK(hipStreamCreateWithFlags(&io.up, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&io.run, hipStreamNonBlocking));
@@ -1194,40 +1213,47 @@ static int host_io_prepare(RNNoiseBatch *b, int frames, bool bounce) {
     HIP_OK(hipEventCreateWithFlags(&io.down_done[k], hipEventDisableTiming));
   }
   io.chunk_frames = frames;
+  io.pcm_floats = n_in;
   return 0;
 }
 
-extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
-                                     int n_frames) {
-  if (!b || !out || !in || n_frames < 0) return -1;
+static int batch_process_host_impl(RNNoiseBatch *b, void *out_v, const void *in_v, float *vad, float *gains, int n_frames,
+                                   bool s16) {
+  if (!b || !out_v || !in_v || n_frames < 0) return -1;
   if (n_frames == 0) return 0;
   ON_DEVICE(b->device);
-  const size_t N = b->n, fsz = N * RN_FRAME_SIZE;
+  const size_t esz = s16 ? sizeof(short) : sizeof(float);
+  const size_t N = b->n, fsz = N * RN_FRAME_SIZE * esz;  // bytes of PCM per frame step
+  const char *in = static_cast<const char *>(in_v);
+  char *out = static_cast<char *>(out_v);
   // chunks of about 32 MB of PCM each way (at least one frame), two in flight.  Pinned caller memory is used in place;
   // pageable memory goes through pinned bounce buffers (the copy in and out of them is then the calling thread's work).
-  const int chunk = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, ((size_t)32 << 20) / (fsz * sizeof(float))));
+  // ... but at least four frames while that stays under 512 MB: a one-frame chunk is a one-frame device call, which runs its
+  // four kernels back to back instead of as the three-stream frame pipeline (65,536 streams: 63 MB of s16 PCM per frame)
+  const size_t by_bytes = std::max<size_t>(1, ((size_t)32 << 20) / fsz), four = std::min<size_t>(4, std::max<size_t>(1, ((size_t)512 << 20) / fsz));
+  const int chunk = (int)std::min<size_t>((size_t)n_frames, std::max(by_bytes, four));
   const bool direct = host_pinned(in) && host_pinned(out) && (!vad || host_pinned(vad)) && (!gains || host_pinned(gains));
-  if (host_io_prepare(b, chunk, !direct)) return -1;
+  if (host_io_prepare(b, chunk, esz, !direct)) return -1;
   RNNoiseBatch::HostIo &io = b->io;
   const int n_chunks = (n_frames + chunk - 1) / chunk;
   auto frames_of = [&](int c) { return std::min(chunk, n_frames - c * chunk); };
   auto upload = [&](int c) -> int {  // chunk c -> staging set c & 1 (free once chunk c-2 has been downloaded)
     const int k = c & 1, f = frames_of(c);
-    const float *src = in + (size_t)c * chunk * fsz;
+    const void *src = in + (size_t)c * chunk * fsz;
     if (c >= 2) HIP_OK(hipStreamWaitEvent(io.up, io.run_done[k], 0));  // its kernels no longer read d_in[k]
     if (!direct) {
       if (c >= 2) HIP_OK(hipEventSynchronize(io.up_done[k]));          // the bounce buffer has been sent
-      memcpy(io.h_in[k], src, (size_t)f * fsz * sizeof(float));
+      memcpy(io.h_in[k], src, (size_t)f * fsz);
       src = io.h_in[k];
     }
-    HIP_OK(hipMemcpyAsync(io.d_in[k], src, (size_t)f * fsz * sizeof(float), hipMemcpyHostToDevice, io.up));
+    HIP_OK(hipMemcpyAsync(io.d_in[k], src, (size_t)f * fsz, hipMemcpyHostToDevice, io.up));
     HIP_OK(hipEventRecord(io.up_done[k], io.up));
     return 0;
   };
   auto collect = [&](int c) -> int {  // pageable callers: bounce buffer of chunk c -> caller memory
     const int k = c & 1, f = frames_of(c);
     HIP_OK(hipEventSynchronize(io.down_done[k]));
-    memcpy(out + (size_t)c * chunk * fsz, io.h_out[k], (size_t)f * fsz * sizeof(float));
+    memcpy(out + (size_t)c * chunk * fsz, io.h_out[k], (size_t)f * fsz);
     if (vad) memcpy(vad + (size_t)c * chunk * N, io.h_vad[k], (size_t)f * N * sizeof(float));
     if (gains) memcpy(gains + (size_t)c * chunk * N * RN_NB_BANDS, io.h_gains[k], (size_t)f * N * RN_NB_BANDS * sizeof(float));
     return 0;
@@ -1238,12 +1264,12 @@ extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *i
     if (c + 1 < n_chunks && upload(c + 1)) return -1;
     HIP_OK(hipStreamWaitEvent(io.run, io.up_done[k], 0));
     if (c >= 2) HIP_OK(hipStreamWaitEvent(io.run, io.down_done[k], 0));  // d_out[k] of chunk c-2 has left
-    if (rnnoise_batch_process_device(b, io.d_out[k], io.d_in[k], io.d_vad[k], io.d_gains[k], f, io.run)) return -1;
+    if (batch_process_device_impl(b, io.d_out[k], io.d_in[k], io.d_vad[k], io.d_gains[k], f, io.run, s16)) return -1;
     HIP_OK(hipEventRecord(io.run_done[k], io.run));
     if (!direct && c >= 2 && collect(c - 2)) return -1;  // frees h_out[k] for the download queued below
     HIP_OK(hipStreamWaitEvent(io.down, io.run_done[k], 0));
-    float *dst_out = direct ? out + (size_t)c * chunk * fsz : io.h_out[k];
-    HIP_OK(hipMemcpyAsync(dst_out, io.d_out[k], (size_t)f * fsz * sizeof(float), hipMemcpyDeviceToHost, io.down));
+    void *dst_out = direct ? static_cast<void *>(out + (size_t)c * chunk * fsz) : io.h_out[k];
+    HIP_OK(hipMemcpyAsync(dst_out, io.d_out[k], (size_t)f * fsz, hipMemcpyDeviceToHost, io.down));
     if (vad) HIP_OK(hipMemcpyAsync(direct ? vad + (size_t)c * chunk * N : io.h_vad[k], io.d_vad[k], (size_t)f * N * sizeof(float),
                                    hipMemcpyDeviceToHost, io.down));
     if (gains) HIP_OK(hipMemcpyAsync(direct ? gains + (size_t)c * chunk * N * RN_NB_BANDS : io.h_gains[k], io.d_gains[k],
@@ -1256,6 +1282,16 @@ extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *i
   HIP_OK(hipStreamSynchronize(io.down));
   HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
   return 0;
+}
+
+extern "C" int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
+                                     int n_frames) {
+  return batch_process_host_impl(b, out, in, vad, gains, n_frames, false);
+}
+
+extern "C" int rnnoise_batch_process_s16(RNNoiseBatch *b, short *out, const short *in, float *vad, float *gains,
+                                         int n_frames) {
+  return batch_process_host_impl(b, out, in, vad, gains, n_frames, true);
 }
 
 // ---- training-feature extraction (reference loop src/dump_features.c:466-491) ----
@@ -1638,10 +1674,10 @@ int pool_step(StatePool *p, int slot, int parity, int ring_slot, long frame_no, 
   }
   g.vad = d_vad;
   const int prev = (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
-  HIP_OK(rn_launch_hp(&g, d_in, ring_slot, st, nullptr, nullptr));
+  HIP_OK(rn_launch_hp(&g, d_in, 0, ring_slot, st, nullptr, nullptr));
   HIP_OK(rn_launch_analysis(&g, &b->tb, ring_slot, parity, st, nullptr, nullptr));
   HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, nullptr, nullptr));
-  HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out, parity, prev, st, nullptr, nullptr));
+  HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out, 0, parity, prev, st, nullptr, nullptr));
   return 0;
 }
 
