@@ -260,10 +260,14 @@ def parity_leg(capi, torch, batch, blob, d_in, n_frames: int, s16: bool):
     xin = x.to(torch.int16) if s16 else x.contiguous()
     vad = torch.empty((n_frames, N), device=dev)
     gains = torch.empty((n_frames, N, 32), device=dev)
+    dbg = (lambda m: print(f"[parity] {m}", file=sys.stderr, flush=True)) if os.environ.get("BENCH_TRACE") else (lambda m: None)
+    dbg("allocated")
     batch.reset()
+    dbg("reset")
     batch.process_device(out.data_ptr(), xin.data_ptr(), vad.data_ptr(), gains.data_ptr(), n_frames,
                          torch.cuda.current_stream().cuda_stream, s16=s16)
     torch.cuda.synchronize()
+    dbg("processed")
     idx = torch.tensor(sample, device=dev)
     got_o, got_v, got_g = out[:, idx].cpu().numpy(), vad[:, idx].cpu().numpy(), gains[:, idx].cpu().numpy()
     pcm = x[:, idx].cpu().numpy()
@@ -384,7 +388,7 @@ def bench_rank(a) -> dict | None:
         # inputs resident in HBM; cycle through at most `cap` distinct frames if K+W is large
         cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))
         if a.host_io:
-            cap = max(4, min(cap, (1 << 30) // (N * FRAME * 4)))  # pinned host memory: 1 GB each way at most
+            cap = max(4, min(cap, (2 << 30) // (N * FRAME * (2 if a.s16 else 4))))  # pinned host memory: 2 GB each way at most
         d_in = d_in_f32 = synth_pcm_torch(torch, N, cap, dev, seed_base=mine.start)
         if a.s16:
             d_in = d_in.to(torch.int16)  # (the synthetic samples are s16-rounded already: exact)
@@ -423,7 +427,11 @@ def bench_rank(a) -> dict | None:
         run(Wm + r * K, K)
         barrier()
         times.append(time.perf_counter() - t0)
+    if os.environ.get("BENCH_TRACE"):
+        print("[bench] timed region done", file=sys.stderr, flush=True)
     kms = batch.kernel_ms()
+    if os.environ.get("BENCH_TRACE"):
+        print("[bench] kernel_ms read", file=sys.stderr, flush=True)
     # the same K steps once more with every kernel on ONE stream: stand-alone kernel durations (in the pipelined schedule
     # the kernels of neighbouring frames share the machine, which stretches each one's own duration)
     kms_alone = None

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);
 #endif
 extern "C" hipError_t rn_launch_state_gather(const RnGroupDev *, float *, int, int, hipStream_t);
 extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *, const float *, int, int, hipStream_t);
+extern "C" hipError_t rn_launch_copy_to_host(void *, const void *, size_t, int, hipStream_t);
 
 
 // Every entry point works on the batch's device and leaves the calling thread's current device as it found it
@@ -570,6 +572,11 @@ struct RNNoiseBatch {
     float *h_in[2] = {}, *h_out[2] = {}, *h_vad[2] = {}, *h_gains[2] = {};
     int chunk_frames = 0;
     size_t pcm_floats = 0;  // capacity of d_in / d_out (and h_in / h_out) of one chunk
+    // pinned callers: a ring of RING frame slots, filled and drained frame by frame beside the kernels
+    static constexpr int RING = 6;
+    char *ring_mem = nullptr;
+    size_t ring_frame_bytes = 0;   // PCM bytes of one slot (sized for float frames)
+    hipEvent_t r_k3[RING] = {}, r_down[RING] = {}, r_up[RING] = {}, r_hp[RING] = {};
   } io;
   // timing
   bool timing = false;
@@ -980,8 +987,8 @@ extern "C" void rnnoise_batch_destroy(RNNoiseBatch *b) {
   if (b->state_stage) hipFree(b->state_stage);
   if (b->arena) hipFree(b->arena);
   if (b->debug_buf) hipFree(b->debug_buf);
-  if (b->side) {
-    hipStreamDestroy(b->side);
+  if (b->side) hipStreamDestroy(b->side);
+  if (b->side_hp) {
     hipStreamDestroy(b->side_hp);
     hipEventDestroy(b->ev_begin);
     for (int k = 0; k < 8; k++) { hipEventDestroy(b->own_hp[k]); hipEventDestroy(b->own_k1[k]); hipEventDestroy(b->own_k3[k]); }
@@ -994,7 +1001,11 @@ extern "C" int rnnoise_batch_size(const RNNoiseBatch *b) { return b ? b->n : -1;
 extern "C" int rnnoise_batch_reset(RNNoiseBatch *b) {
   if (!b) return -1;
   ON_DEVICE(b->device);
+  // a control operation, synchronous like state export / import: whatever the batch (or anybody else) still has in flight on
+  // this device is drained first, and the cleared state is in place when the call returns
+  HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemset(b->arena, 0, b->arena_bytes));
+  HIP_OK(hipDeviceSynchronize());
   b->img_valid = false;
   b->parity = 0;
   b->ring_slot = 0;
@@ -1017,16 +1028,25 @@ extern "C" int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path) {
   return old;
 }
 
+// Hooks of the host-fed path: the frame buffers of a call are then a ring of `ring` frame slots in HBM (frame f lives in
+// slot f % ring) that uploads fill and downloads drain while the kernels run; each hook is called on the host right where
+// the named kernel of frame f is enqueued, with the stream it goes to.
+struct FrameIoHooks {
+  int ring = 0;
+  std::function<int(int, hipStream_t)> before_hp, after_hp, before_nn, after_k3;
+};
+
 // PCM frames are float (the reference API's sample type) or, with s16 set, int16 converted at the two ends of the step as the
 // reference's only caller does (examples/rnnoise_demo.c:56,58): half the bytes over HBM and, in the host-fed path, PCIe.
 static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v, float *d_vad, float *d_gains,
-                                     int n_frames, void *hip_stream, bool s16) {
+                                     int n_frames, void *hip_stream, bool s16, const FrameIoHooks *hk = nullptr) {
   if (!b || !d_out_v || !d_in_v || n_frames < 0) return -1;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   ON_DEVICE(b->device);
   const size_t N = b->n, esz = s16 ? sizeof(short) : sizeof(float);
   const char *d_in = static_cast<const char *>(d_in_v);
   char *d_out = static_cast<char *>(d_out_v);
+  auto buf = [&](int f) -> size_t { return hk ? (size_t)(f % hk->ring) : (size_t)f; };  // frame f's place in the caller's buffers
   // Multi-frame calls are software-pipelined over three streams: C runs the high-pass of frames up to
   // f+2, B the analysis of frame f+1, A (the caller's stream) network + synthesis of frame f.
   // What makes that legal:
@@ -1042,8 +1062,8 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
   const int pipe_force = b->schedule ? b->schedule : pipe_env;
   const bool pipelined = n_frames > 1 && pipe_force != 9;
   const bool side_k1 = pipelined && pipe_force != 1;
-  if (pipelined && !b->side) {
-    HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  if (side_k1 && !b->side) HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  if (pipelined && !b->side_hp) {
     HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
     // ordering between streams of ONE device: no system-scope fence (it writes back and invalidates the caches at
     // every record, which the next kernels then pay for)
@@ -1067,8 +1087,8 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
     g.features = b->features2[c];
     g.silence = b->silence2[c];
     g.pitch = b->pitch2[c];
-    g.vad = d_vad ? d_vad + f * N : b->scratch_vad;
-    g.gains = d_gains ? d_gains + f * N * RN_NB_BANDS : b->scratch_gains;
+    g.vad = d_vad ? d_vad + buf(f) * N : b->scratch_vad;
+    g.gains = d_gains ? d_gains + buf(f) * N * RN_NB_BANDS : b->scratch_gains;
     return g;
   };
   auto highpass = [&](int f) -> int {  // K0 of frame f on stream sc
@@ -1082,10 +1102,14 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
     // (4 waves x 56 VGPRs per SIMD) it costs nothing.
     static const bool hp_early = getenv("RNNOISE_AMD_HP_EARLY") != nullptr;  // A/B runs only: the ring-bound start
     if (side_k1 && f >= 4 && !hp_early) HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[(f - 4) & 7], 0));
-    TimedLaunch t(b, 3);
-    b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
-    HIP_OK(rn_launch_hp(&b->g, d_in + f * N * RN_FRAME_SIZE * esz, s16, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
-                        b->cur_hp[f & 7]));
+    if (hk && hk->before_hp(f, sc)) return -1;
+    {
+      TimedLaunch t(b, 3);
+      b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
+      HIP_OK(rn_launch_hp(&b->g, d_in + buf(f) * N * RN_FRAME_SIZE * esz, s16, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
+                          b->cur_hp[f & 7]));
+    }
+    if (hk && hk->after_hp(f, sc)) return -1;
     return 0;
   };
   auto analysis = [&](int f) -> int {  // K1 of frame f on stream sb
@@ -1117,6 +1141,7 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
       if (f + 1 < n_frames && analysis(f + 1)) return -1;
       if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->cur_k1[f & 7], 0));
     }
+    if (hk && hk->before_nn(f, st)) return -1;
     {
       // (the layer images are indexed by tile of the whole batch; the layer kernels use 32-bit byte offsets into a state plane)
       const bool whole = g.n_streams == g.n_stride && (size_t)g.n_streams * RN_GRU * 4 < (1ull << 32);
@@ -1138,8 +1163,9 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
     {
       TimedLaunch t(b, 2);
       b->cur_k3[f & 7] = t.on ? t.stop() : (side_k1 ? b->own_k3[f & 7] : nullptr);
-      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + f * N * RN_FRAME_SIZE * esz, s16, cur, prev, st, t.start(), b->cur_k3[f & 7]));
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + buf(f) * N * RN_FRAME_SIZE * esz, s16, cur, prev, st, t.start(), b->cur_k3[f & 7]));
     }
+    if (hk && hk->after_k3(f, st)) return -1;
     b->launches += b->timing ? 1 : 0;
   }
   b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;
@@ -1177,7 +1203,11 @@ static void host_io_release(RNNoiseBatch *b) {
     if (io.h_in[k]) hipHostFree(io.h_in[k]);
     if (io.up_done[k]) { hipEventDestroy(io.up_done[k]); hipEventDestroy(io.run_done[k]); hipEventDestroy(io.down_done[k]); }
   }
-  if (io.up) { hipStreamDestroy(io.up); hipStreamDestroy(io.run); hipStreamDestroy(io.down); }
+  if (io.up) hipStreamDestroy(io.up);
+  if (io.run) { hipStreamDestroy(io.run); hipStreamDestroy(io.down); }
+  if (io.ring_mem) hipFree(io.ring_mem);
+  for (int k = 0; k < RNNoiseBatch::HostIo::RING; k++)
+    if (io.r_k3[k]) { hipEventDestroy(io.r_k3[k]); hipEventDestroy(io.r_down[k]); hipEventDestroy(io.r_up[k]); hipEventDestroy(io.r_hp[k]); }
   io = RNNoiseBatch::HostIo();
 }
 
@@ -1217,6 +1247,119 @@ static int host_io_prepare(RNNoiseBatch *b, int frames, size_t esz, bool bounce)
   return 0;
 }
 
+// Host-fed path for pinned caller memory (hipHostMalloc / hipHostRegister): the DMA engines read and write it in place, one
+// frame per copy, while ONE multi-frame device call runs the kernels as the three-stream frame pipeline over a ring of
+// RING frame slots in HBM.  Per frame f: upload(f) [after high-pass(f - RING) has read the slot] -> high-pass(f) -> ... ->
+// network(f), synthesis(f) [after download(f - RING) has drained the slot] -> download(f).  A call pays one frame's upload
+// before and one frame's download after its kernels, whatever its length.
+static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, float *vad, float *gains, int n_frames, bool s16) {
+  RNNoiseBatch::HostIo &io = b->io;
+  constexpr int RING = RNNoiseBatch::HostIo::RING;
+  const size_t N = b->n, esz = s16 ? sizeof(short) : sizeof(float), fsz = N * RN_FRAME_SIZE * esz;
+  if (!io.run) {
+    HIP_OK(hipStreamCreateWithFlags(&io.run, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&io.down, hipStreamNonBlocking));
+  }
+  const size_t slot_pcm = (N * RN_FRAME_SIZE * sizeof(float) + 255) & ~size_t(255), slot_vad = (N * 4 + 255) & ~size_t(255),
+               slot_g = (N * RN_NB_BANDS * 4 + 255) & ~size_t(255);
+  if (!io.ring_mem) {
+    HIP_OK(hipMalloc((void **)&io.ring_mem, RING * (2 * slot_pcm + slot_vad + slot_g)));
+    io.ring_frame_bytes = slot_pcm;
+    for (int k = 0; k < RING; k++) {
+      HIP_OK(hipEventCreateWithFlags(&io.r_k3[k], hipEventDisableTiming));  // (a copy engine follows a kernel: system scope)
+      HIP_OK(hipEventCreateWithFlags(&io.r_down[k], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&io.r_up[k], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&io.r_hp[k], hipEventDisableTiming | hipEventDisableSystemFence));  // (read-after-read ordering only)
+    }
+  }
+  // the slots are addressed with the stride of the CALL's frame size (s16 frames use the first half of a slot's room)
+  char *r_in = io.ring_mem, *r_out = r_in + RING * slot_pcm;
+  float *r_vad = reinterpret_cast<float *>(r_out + RING * slot_pcm), *r_g = reinterpret_cast<float *>(reinterpret_cast<char *>(r_vad) + RING * slot_vad);
+  FrameIoHooks hk;
+  hk.ring = RING;
+  // Uploads ride on the stream of their consumer, the high-pass (1.4 ms of DMA + 0.2 ms of kernel per 65,536-stream s16
+  // frame, in stream order: no events, and upload(f) follows high-pass(f - RING) by construction).  A stream of their own
+  // made five streams with the pipeline's three and the download's: the runtime multiplexes streams onto four hardware
+  // queues, and the two copy directions ended up serialised behind one another (measured: 21 M instead of 29 M frames/s).
+  // $RNNOISE_AMD_HOSTIO_COPY (A/B runs): "one" = uploads and downloads alternate on ONE copy stream, so that each finds the
+  // DMA engine free (two copies in flight make the runtime run one of them as a blit kernel); "hp" = uploads on the
+  // high-pass stream, downloads on the copy stream.
+  static const bool one_copy_stream = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY"); return !e || !strcmp(e, "one"); }();
+  hk.before_hp = [&](int f, hipStream_t sc) -> int {
+    if (!one_copy_stream) {
+      HIP_OK(hipMemcpyAsync(r_in + (size_t)(f % RING) * fsz, in + (size_t)f * fsz, fsz, hipMemcpyHostToDevice, sc));
+      return 0;
+    }
+    if (f >= RING) HIP_OK(hipStreamWaitEvent(io.down, io.r_hp[f % RING], 0));   // high-pass(f - RING) has read the slot
+    HIP_OK(hipMemcpyAsync(r_in + (size_t)(f % RING) * fsz, in + (size_t)f * fsz, fsz, hipMemcpyHostToDevice, io.down));
+    HIP_OK(hipEventRecord(io.r_up[f % RING], io.down));
+    HIP_OK(hipStreamWaitEvent(sc, io.r_up[f % RING], 0));
+    return 0;
+  };
+  hk.after_hp = [&](int f, hipStream_t sc) -> int {
+    if (one_copy_stream) HIP_OK(hipEventRecord(io.r_hp[f % RING], sc));
+    return 0;
+  };
+  hk.before_nn = [&](int f, hipStream_t st) -> int {  // network(f) writes vad / gains, synthesis(f) the PCM of slot f % RING
+    if (f >= RING) HIP_OK(hipStreamWaitEvent(st, io.r_down[f % RING], 0));
+    return 0;
+  };
+  // Downloads: by default a small copy kernel writing the caller's pinned memory through its device address
+  // (state_kernels.hip: rn_copy_to_host_kernel -- the runtime's own D2H turns into a 256-workgroup blit kernel whenever the DMA
+  // engine is busy with an upload, and that kernel doubles the duration of whatever runs beside it); $RNNOISE_AMD_D2H = "dma"
+  // keeps hipMemcpyAsync, "kernel:<workgroups>" sizes the copy kernel (A/B runs).
+  static const int d2h_blocks = [] {
+    const char *e = getenv("RNNOISE_AMD_D2H");
+    if (e && !strncmp(e, "kernel:", 7)) return std::max(1, atoi(e + 7));
+    return 0;
+  }();
+  auto dev_view = [](void *host) -> void * {  // device address of pinned host memory, or nullptr (then: hipMemcpyAsync)
+    void *d = nullptr;
+    if (!host || hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+  };
+  char *out_dev = d2h_blocks ? static_cast<char *>(dev_view(out)) : nullptr;
+  float *vad_dev = d2h_blocks && vad ? static_cast<float *>(dev_view(vad)) : nullptr;
+  float *gains_dev = d2h_blocks && gains ? static_cast<float *>(dev_view(gains)) : nullptr;
+  const bool by_kernel = out_dev && (!vad || vad_dev) && (!gains || gains_dev) && !(reinterpret_cast<uintptr_t>(out_dev) & 15) &&
+                         !(reinterpret_cast<uintptr_t>(vad_dev) & 15) && !(reinterpret_cast<uintptr_t>(gains_dev) & 15) && N % 4 == 0;
+  hk.after_k3 = [&](int f, hipStream_t st) -> int {
+    const int k = f % RING;
+    HIP_OK(hipEventRecord(io.r_k3[k], st));
+    HIP_OK(hipStreamWaitEvent(io.down, io.r_k3[k], 0));
+    if (by_kernel) {
+      HIP_OK(rn_launch_copy_to_host(out_dev + (size_t)f * fsz, r_out + (size_t)k * fsz, fsz, d2h_blocks, io.down));
+      if (vad) HIP_OK(rn_launch_copy_to_host(vad_dev + (size_t)f * N, r_vad + (size_t)k * N, N * sizeof(float), 1, io.down));
+      if (gains) HIP_OK(rn_launch_copy_to_host(gains_dev + (size_t)f * N * RN_NB_BANDS, r_g + (size_t)k * N * RN_NB_BANDS,
+                                               N * RN_NB_BANDS * sizeof(float), std::max(1, d2h_blocks / 4), io.down));
+    } else {
+      HIP_OK(hipMemcpyAsync(out + (size_t)f * fsz, r_out + (size_t)k * fsz, fsz, hipMemcpyDeviceToHost, io.down));
+      if (vad) HIP_OK(hipMemcpyAsync(vad + (size_t)f * N, r_vad + (size_t)k * N, N * sizeof(float), hipMemcpyDeviceToHost, io.down));
+      if (gains) HIP_OK(hipMemcpyAsync(gains + (size_t)f * N * RN_NB_BANDS, r_g + (size_t)k * N * RN_NB_BANDS, N * RN_NB_BANDS * sizeof(float),
+                                       hipMemcpyDeviceToHost, io.down));
+    }
+    HIP_OK(hipEventRecord(io.r_down[k], io.down));
+    return 0;
+  };
+  // Stream budget: the runtime multiplexes HIP streams onto four hardware queues, one of which belongs to the application's
+  // own stream.  The three-stream frame pipeline plus the download stream would be four more, and the high-pass and analysis
+  // streams then share a queue: uploads (on the high-pass stream) queue up behind analysis kernels and the whole step
+  // serialises (rocprofv3 trace: 3.5 ms per 65,536-stream s16 step).  Analysis therefore stays on the main stream here
+  // (schedule 1: only uploads + high-pass run ahead on a side stream), which costs the 2-3 % the analysis overlap is worth.
+  static const int sched_env = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_SCHEDULE"); return e ? atoi(e) : 1; }();  // (A/B runs)
+  const int keep = b->schedule;
+  if (b->schedule == 0) b->schedule = sched_env;
+  const int rc = batch_process_device_impl(b, r_out, r_in, r_vad, r_g, n_frames, io.run, s16, &hk);
+  b->schedule = keep;
+  if (rc) {
+    (void)hipDeviceSynchronize();  // whatever was queued must not outlive the caller's buffers
+    return -1;
+  }
+  HIP_OK(hipStreamSynchronize(io.down));
+  HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
+  return 0;
+}
+
 static int batch_process_host_impl(RNNoiseBatch *b, void *out_v, const void *in_v, float *vad, float *gains, int n_frames,
                                    bool s16) {
   if (!b || !out_v || !in_v || n_frames < 0) return -1;
@@ -1226,13 +1369,11 @@ static int batch_process_host_impl(RNNoiseBatch *b, void *out_v, const void *in_
   const size_t N = b->n, fsz = N * RN_FRAME_SIZE * esz;  // bytes of PCM per frame step
   const char *in = static_cast<const char *>(in_v);
   char *out = static_cast<char *>(out_v);
-  // chunks of about 32 MB of PCM each way (at least one frame), two in flight.  Pinned caller memory is used in place;
-  // pageable memory goes through pinned bounce buffers (the copy in and out of them is then the calling thread's work).
-  // ... but at least four frames while that stays under 512 MB: a one-frame chunk is a one-frame device call, which runs its
-  // four kernels back to back instead of as the three-stream frame pipeline (65,536 streams: 63 MB of s16 PCM per frame)
-  const size_t by_bytes = std::max<size_t>(1, ((size_t)32 << 20) / fsz), four = std::min<size_t>(4, std::max<size_t>(1, ((size_t)512 << 20) / fsz));
-  const int chunk = (int)std::min<size_t>((size_t)n_frames, std::max(by_bytes, four));
   const bool direct = host_pinned(in) && host_pinned(out) && (!vad || host_pinned(vad)) && (!gains || host_pinned(gains));
+  if (direct) return batch_process_pinned(b, out, in, vad, gains, n_frames, s16);
+  // Pageable memory goes through pinned bounce buffers (the copy in and out of them is the calling thread's work): chunks of
+  // about 32 MB of PCM each way (at least one frame), two in flight.
+  const int chunk = (int)std::min<size_t>((size_t)n_frames, std::max<size_t>(1, ((size_t)32 << 20) / fsz));
   if (host_io_prepare(b, chunk, esz, !direct)) return -1;
   RNNoiseBatch::HostIo &io = b->io;
   const int n_chunks = (n_frames + chunk - 1) / chunk;

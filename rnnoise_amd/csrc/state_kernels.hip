@@ -72,3 +72,34 @@ extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *g, const float *
   hipLaunchKernelGGL(rn_state_scatter_kernel, dim3(g->n_streams), dim3(256), 0, st, *g, flat, newest_slot, last);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device -> pinned-host copy by a SMALL kernel (host-fed path, shim.cpp: batch_process_pinned).  hipMemcpyAsync finds the
+// DMA engine busy with the upload running the other way and falls back to the runtime's blit kernel -- 256 workgroups of
+// 512 lanes whose PCIe-bound stores fill the memory pipeline of every CU: the analysis kernel running beside it takes
+// 2.3 ms instead of 1.1 (rocprofv3 trace).  Posted writes over PCIe need few lanes to fill the link, so this copy runs on
+// `blocks` workgroups (default 32) at the lowest wave priority.
+// ---------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+rn_copy_to_host_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16, uint32_t *__restrict__ dst_tail,
+                       const uint32_t *__restrict__ src_tail, int n_tail) {
+  __builtin_amdgcn_s_setprio(0);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {  // four 16-byte loads in flight per lane
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+// bytes: a multiple of 4; dst / src 16-byte aligned
+extern "C" hipError_t rn_launch_copy_to_host(void *dst, const void *src, size_t bytes, int blocks, hipStream_t st) {
+  const size_t n16 = bytes / 16;
+  const int n_tail = (int)((bytes % 16) / 4);
+  hipLaunchKernelGGL(rn_copy_to_host_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint4 *>(dst), static_cast<const uint4 *>(src), n16,
+                     reinterpret_cast<uint32_t *>(static_cast<char *>(dst) + 16 * n16),
+                     reinterpret_cast<const uint32_t *>(static_cast<const char *>(src) + 16 * n16), n_tail);
+  return hipGetLastError();
+}

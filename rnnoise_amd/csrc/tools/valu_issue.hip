@@ -22,7 +22,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 enum Op { FMA32, ADD32, MUL32, ADD32_DPP_ROWSHR, ADD32_DPP_QUAD, MOV_DPP_ROWROR, PKADD32, PKFMA32, PKMUL32, FMA64, ADD64, MUL64, DOT4, ADDU32, MADU24,
           MED3, CVTPKU8, RCP32, EXP32, PERM, CNDMASK, CMP32, DSREAD32, DSREAD64, DSREAD128, DSSWIZZLE, DSBPERMUTE, PERMLANE32SWAP, FMA32_DSREAD, FMA32_SALU, NOPS,
-          MOV32, AND32, LSHL32, XOR32, MAX32, SUB32, CNDMASK_S, CMP_S, BFE32, LSHLADD, READLANE, MULLO, ADD32_SGPR, MUL32_LIT, DSWRITE32, DSWRITE128, DSREADU16, DPP_WAVESHR, ADD3, CNDMASK_E64VCC, CMP_CND_VCC, CMP_CND_S, CNDMASK_VCC_INIT, CMP_CND2, CMP_CND4, CND_ADD, CMP_ADD_CND2 };
+          MOV32, AND32, LSHL32, XOR32, MAX32, SUB32, CNDMASK_S, CMP_S, BFE32, LSHLADD, READLANE, MULLO, ADD32_SGPR, MUL32_LIT, DSWRITE32, DSWRITE128, DSREADU16, DPP_WAVESHR, ADD3, CNDMASK_E64VCC, CMP_CND_VCC, CMP_CND_S, CNDMASK_VCC_INIT, CMP_CND2, CMP_CND4, CND_ADD, CMP_ADD_CND2, DPP_FMA, F64_FMA, LSHL_FMA, MAX_FMA };
 static const char *OPN[] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_f32 dpp row_shr:1", "v_add_f32 dpp quad_perm", "v_mov_b32 dpp row_ror:8", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mul_f32",
                             "v_fma_f64", "v_add_f64", "v_mul_f64", "v_dot4_i32_i8", "v_add_u32", "v_mad_u32_u24", "v_med3_f32", "v_cvt_pk_u8_f32", "v_rcp_f32", "v_exp_f32", "v_perm_b32",
                             "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b32", "ds_read_b64", "ds_read_b128", "ds_swizzle_b32", "ds_bpermute_b32", "v_permlane32_swap", "v_fma_f32 + ds_read_b32 (1:1)",
@@ -30,7 +30,8 @@ static const char *OPN[] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_f32 dp
                             "v_mov_b32", "v_and_b32", "v_lshlrev_b32", "v_xor_b32", "v_max_f32", "v_sub_f32", "v_cndmask_b32 (sgpr mask)", "v_cmp_lt_f32 -> sgpr pair", "v_bfe_u32", "v_lshl_add_u32",
                             "v_readlane_b32", "v_mul_lo_u32", "v_add_f32 (sgpr operand)", "v_mul_f32 (literal)", "ds_write_b32", "ds_write_b128", "ds_read_u16", "v_add_f32 dpp wave_shr:1", "v_add3_u32",
                             "v_cndmask_b32_e64 (vcc spelled)", "v_cmp->vcc + v_cndmask vcc (pair)", "v_cmp->sgpr + v_cndmask sgpr (pair)", "v_cndmask_b32 vcc (vcc set before)",
-                            "v_cmp->vcc + 2 x v_cndmask vcc", "v_cmp->vcc + 4 x v_cndmask vcc", "v_cndmask vcc + v_add_f32 (1:1)", "v_cmp->vcc, add, cnd, add, cnd"};
+                            "v_cmp->vcc + 2 x v_cndmask vcc", "v_cmp->vcc + 4 x v_cndmask vcc", "v_cndmask vcc + v_add_f32 (1:1)", "v_cmp->vcc, add, cnd, add, cnd",
+                            "v_add_f32 dpp + v_fma_f32 (1:1)", "v_fma_f64 + v_fma_f32 (1:1)", "v_lshlrev_b32 + v_fma_f32 (1:1)", "v_max_f32 + v_fma_f32 (1:1)"};
 constexpr int UNROLL = 64;
 
 // UNROLL = 64 instructions on 8 (or 1, NACC == 1) accumulators, as ONE asm statement (hipcc puts an s_nop after every
@@ -102,6 +103,8 @@ constexpr int UNROLL = 64;
 #define T_CMPCND4(n) "v_cmp_lt_f32 vcc, %" #n ", %[c0]\n v_cndmask_b32 %" #n ", %" #n ", %[c0], vcc\n v_cndmask_b32 %" #n ", %" #n ", %[c1], vcc\n v_cndmask_b32 %" #n ", %" #n ", %[c0], vcc\n v_cndmask_b32 %" #n ", %" #n ", %[c1], vcc\n"
 #define T_CNDADD(n) "v_cndmask_b32 %" #n ", %" #n ", %[c0], vcc\n v_add_f32 %" #n ", %" #n ", %[c1]\n"
 #define T_CMPADDCND2(n) "v_cmp_lt_f32 vcc, %" #n ", %[c0]\n v_add_f32 %" #n ", %" #n ", %[c1]\n v_cndmask_b32 %" #n ", %" #n ", %[c0], vcc\n v_add_f32 %" #n ", %" #n ", %[c1]\n v_cndmask_b32 %" #n ", %" #n ", %[c1], vcc\n"
+#define T_DPPFMA(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:1 row_mask:0xf bank_mask:0xf\n v_fma_f32 %" #n ", %" #n ", %[c0], %[c1]\n"
+#define T_MAXFMA(n) "v_max_f32 %" #n ", %" #n ", %[c0]\n v_fma_f32 %" #n ", %" #n ", %[c0], %[c1]\n"
 #define T_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %[ad], %[ad]\n"
 template <int OP, int NACC>
 __device__ __forceinline__ void body(float (&a)[8], v2f (&p)[8], double (&d)[8], int (&n)[8], v4f (&q)[8], float c0, float c1, int lds_addr) {
@@ -165,6 +168,10 @@ __device__ __forceinline__ void body(float (&a)[8], v2f (&p)[8], double (&d)[8],
   if constexpr (OP == CMP_CND_VCC) EMIT(T_CMPCNDV, a);
   if constexpr (OP == CMP_CND_S) EMIT(T_CMPCNDS, a);
   if constexpr (OP == CNDMASK_VCC_INIT) EMIT(T_CNDMASK, a);
+  if constexpr (OP == DPP_FMA) EMIT(T_DPPFMA, a);
+  if constexpr (OP == MAX_FMA) EMIT(T_MAXFMA, a);
+  if constexpr (OP == F64_FMA) { EMIT(T_FMA64, d); EMIT(T_FMA32, a); }
+  if constexpr (OP == LSHL_FMA) { EMIT(T_LSHL, n); EMIT(T_FMA32, a); }
   if constexpr (OP == CMP_CND2) EMIT(T_CMPCND2, a);
   if constexpr (OP == CMP_CND4) EMIT(T_CMPCND4, a);
   if constexpr (OP == CND_ADD) EMIT(T_CNDADD, a);
@@ -227,7 +234,7 @@ static Res run(int W, int B, int iters, uint64_t *dT, float *dS) {
   launch<OP, NACC>(blocks, threads, ldsb, iters / 8 + 1, dT, dS, h1, ms0);  // warm-up (clocks, code)
   launch<OP, NACC>(blocks, threads, ldsb, iters, dT, dS, h1, ms1);
   launch<OP, NACC>(blocks, threads, ldsb, 2 * iters, dT, dS, h2, ms2);
-  const double per = (OP == FMA32_DSREAD || OP == FMA32_SALU || OP == CMP_CND_VCC || OP == CMP_CND_S || OP == CND_ADD) ? 2 : (OP == CMP_CND2 ? 3 : ((OP == CMP_CND4 || OP == CMP_ADD_CND2) ? 5 : 1)), ninst = double(iters) * UNROLL * per;
+  const double per = (OP == FMA32_DSREAD || OP == FMA32_SALU || OP == CMP_CND_VCC || OP == CMP_CND_S || OP == CND_ADD || OP == DPP_FMA || OP == F64_FMA || OP == LSHL_FMA || OP == MAX_FMA) ? 2 : (OP == CMP_CND2 ? 3 : ((OP == CMP_CND4 || OP == CMP_ADD_CND2) ? 5 : 1)), ninst = double(iters) * UNROLL * per;
   // (1) slope of the mean wave time between the two launches = ticks for `ninst` more instructions per wave
   double s1 = 0, s2 = 0;
   for (int w = 0; w < waves; w++) { s1 += double(h1[3 * w + 1] - h1[3 * w]); s2 += double(h2[3 * w + 1] - h2[3 * w]); }
@@ -275,6 +282,7 @@ int main(int argc, char **argv) {
   if (argc > 1 && !strcmp(argv[1], "cnd")) {  // only the select forms
     row<CNDMASK>(dT, dS, it); row<CNDMASK_VCC_INIT>(dT, dS, it); row<CNDMASK_E64VCC>(dT, dS, it); row<CNDMASK_S>(dT, dS, it); row<CMP_CND_VCC>(dT, dS, it); row<CMP_CND_S>(dT, dS, it);
     row<CMP_CND2>(dT, dS, it); row<CMP_CND4>(dT, dS, it); row<CND_ADD>(dT, dS, it); row<CMP_ADD_CND2>(dT, dS, it);
+    row<DPP_FMA>(dT, dS, it); row<MAX_FMA>(dT, dS, it); row<F64_FMA>(dT, dS, it); row<LSHL_FMA>(dT, dS, it);
     return 0;
   }
   row<FMA32>(dT, dS, it); row<ADD32>(dT, dS, it); row<MUL32>(dT, dS, it); row<ADD32_DPP_ROWSHR>(dT, dS, it); row<ADD32_DPP_QUAD>(dT, dS, it); row<MOV_DPP_ROWROR>(dT, dS, it);
@@ -288,5 +296,6 @@ int main(int argc, char **argv) {
   row<MUL32_LIT>(dT, dS, it); row<DPP_WAVESHR>(dT, dS, it); row<DSWRITE32>(dT, dS, it); row<DSWRITE128>(dT, dS, it); row<DSREADU16>(dT, dS, it);
   row<CNDMASK_VCC_INIT>(dT, dS, it); row<CNDMASK_E64VCC>(dT, dS, it); row<CMP_CND_VCC>(dT, dS, it); row<CMP_CND_S>(dT, dS, it);
   row<CMP_CND2>(dT, dS, it); row<CMP_CND4>(dT, dS, it); row<CND_ADD>(dT, dS, it); row<CMP_ADD_CND2>(dT, dS, it);
+  row<DPP_FMA>(dT, dS, it); row<MAX_FMA>(dT, dS, it); row<F64_FMA>(dT, dS, it); row<LSHL_FMA>(dT, dS, it);
   return 0;
 }

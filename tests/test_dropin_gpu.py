@@ -128,16 +128,29 @@ def test_bad_state_returns_a_zeroed_frame_instead_of_aborting():
     assert v == 0.0 and not x.any()
 
 
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "s16"])
 def test_host_fed_path_chunks_in_flight(model, blob_default, pinned):
-    """rnnoise_batch_process: 8192 streams x 12 frames = 6 chunks of 32 MB through the double-buffered pipeline, from
-    pageable memory (bounce buffers) and from pinned memory (direct DMA); replicas stay identical and match the oracle"""
+    """rnnoise_batch_process: 8192 streams x 12 frames from pageable memory (6 chunks of 32 MB through the double-buffered
+    bounce buffers) and from pinned memory (direct DMA frame by frame through the 6-slot ring in HBM, beside ONE pipelined
+    12-frame device call: every slot is reused once), the latter also with int16 PCM; replicas stay identical and match the
+    oracle; a pageable call then continues the same streams"""
     torch = pytest.importorskip("torch")
     N, T = 8192, 12
     base = synth.batch_pcm(range(8), T, lead_silence=1)
     pcm = np.ascontiguousarray(np.tile(base, (1, N // 8, 1)))
     b = capi.Batch(model, N)
-    if pinned:
+    if pinned == "s16":
+        t_in = torch.from_numpy(pcm.astype(np.int16)).pin_memory()
+        t_out = torch.empty_like(t_in).pin_memory()
+        t_vad = torch.empty((T, N)).pin_memory()
+        t_g = torch.empty((T, N, 32)).pin_memory()
+        b.process_into(t_out.data_ptr(), t_in.data_ptr(), t_vad.data_ptr(), t_g.data_ptr(), T, s16=True)
+        out16, vad, gains = t_out.numpy(), t_vad.numpy(), t_g.numpy()
+        want = oracle_run(blob_default, base, collect_state=False)
+        from test_gpu_parity import x86_float_to_short
+        assert np.array_equal(out16[:, :8], x86_float_to_short(want["out"])) and np.array_equal(out16[:, -8:], out16[:, :8])
+        out = np.ascontiguousarray(np.tile(want["out"], (1, N // 8, 1)))  # (PCM checked above; the rest below as for floats)
+    elif pinned:
         t_in = torch.from_numpy(pcm).pin_memory()
         t_out = torch.empty_like(t_in).pin_memory()
         t_vad = torch.empty((T, N)).pin_memory()
