@@ -5,6 +5,7 @@
 // Numerics contract as in dsp_kernels.hip: -ffp-contract=off, reference order of every float sum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rn_dev.h"
 
 #define WAVE 64
@@ -181,8 +182,186 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K0 for a handful of streams (the one-stream states behind rnnoise_process_frame, and batches of up to 64 streams): the
+// same arithmetic with ONE WAVE PER STREAM instead of one lane, arranged for latency.  What is serial stays serial -- the
+// biquad recurrence runs once per wave (every lane computes the same values from broadcast LDS reads), each autocorrelation
+// lag is one lane's chain in the reference's order -- but the five lags run side by side on lanes 0-4 instead of one after
+// the other in a lane, the 2x decimation is spread over the wave, and global memory is touched in coalesced rows only
+// (frame and pitch_buf come in through LDS).  43 us -> about 13 us for one stream.
+// ---------------------------------------------------------------------------------------------
+struct HpOneLds {
+  float pb[RN_PITCH_BUF_SIZE];  // pitch_buf of this frame: 1248 old samples from the ring, then the 480 just filtered
+  float xin[RN_FRAME_SIZE];
+  float xlp[864 + 64 + 8];      // decimated signal (+ room for the reads of the idle lanes of the lag chains)
+};
 
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int in_s16) {
+  __shared__ __attribute__((aligned(16))) HpOneLds L;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
+  const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
+  float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
+  float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
+  const int ring0 = RN_RING0(slot);
+  {  // frame -> xin (120 float4), old part of pitch_buf -> pb (312 float4; ring0 and the ring size are multiples of 32)
+    const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
+    const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
+    float4 f[2], o[5];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int q = min(lane + 64 * i, RN_FRAME_SIZE / 4 - 1);  // (lanes past the end re-read the last 16 bytes and drop them)
+      if (in_s16) {
+        const short4 v = x16[q];
+        f[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+      } else {
+        f[i] = x[q];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int q = min(lane + 64 * i, (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4 - 1);
+      int p = ring0 + 4 * q;
+      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
+      o[i] = *reinterpret_cast<const float4 *>(ring + p);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (lane + 64 * i < RN_FRAME_SIZE / 4) reinterpret_cast<float4 *>(L.xin)[lane + 64 * i] = f[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+      if (lane + 64 * i < (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
+  }
+  __syncthreads();
+  // rnn_biquad (src/denoise.c:409-419), once per wave: every lane reads the same samples and computes the same states
+  {
+    const float4 *xi4 = reinterpret_cast<const float4 *>(L.xin);
+    float4 *yo4 = reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE));
+    constexpr int BLK = 8;
+    float4 cur[BLK], nxt[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) nxt[j] = xi4[j];
+    for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+      if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
+#pragma unroll
+        for (int j = 0; j < BLK; j++) nxt[j] = xi4[(blk + 1) * BLK + j];
+      }
+#define HP_STEP(xi, yo)                                              \
+      {                                                              \
+        const float yi = (xi) + m0;                                  \
+        const double xd = (double)(xi), yd = (double)yi;             \
+        m0 = (float)((double)m1 + fma(na0, yd, b0d * xd));           \
+        m1 = (float)fma(na1, yd, xd);                                \
+        (yo) = yi;                                                   \
+      }
+#pragma unroll
+      for (int j = 0; j < BLK; j++) {
+        const float4 v = cur[j];
+        float4 o;
+        HP_STEP(v.x, o.x) HP_STEP(v.y, o.y) HP_STEP(v.z, o.z) HP_STEP(v.w, o.w)
+        if (lane == ((blk * BLK + j) & 63)) yo4[blk * BLK + j] = o;  // (one writer per 16 bytes)
+      }
+#undef HP_STEP
+    }
+    if (lane == 0) {
+      g.mem_hp[2 * s] = m0;
+      g.mem_hp[2 * s + 1] = m1;
+    }
+  }
+  __syncthreads();
+  {  // the filtered frame -> its ring slot (coalesced); 2x decimation of the whole pitch_buf (src/pitch.c:155-160)
+    float4 *y = reinterpret_cast<float4 *>(ring + slot * RN_FRAME_SIZE);
+    const float4 *src = reinterpret_cast<const float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE));
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (lane + 64 * i < RN_FRAME_SIZE / 4) y[lane + 64 * i] = src[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      const int t = lane + 64 * i;
+      if (t < 864) {
+        const float c = L.pb[2 * t], r = L.pb[2 * t + 1];
+        L.xlp[t] = (t == 0) ? .5f * (.5f * r + c) : .5f * (.5f * (L.pb[2 * t - 1] + r) + c);
+      }
+    }
+    if (lane < 8) L.xlp[864 + lane] = 0;
+    L.xlp[872 + lane] = 0;
+  }
+  __syncthreads();
+  // 5-lag autocorrelation (src/celt_lpc.c:92-174): lane k = lag k, terms in the reference's order; terms i >= 860 form the
+  // tail chain d (rnn_pitch_xcorr runs over fastN = 860 terms, the rest is added afterwards)
+  float acl = 0, dl = 0;
+  {
+    const float *xa = L.xlp, *xb = L.xlp + lane;
+#pragma unroll 20
+    for (int i = 0; i < 860; i++) acl = acl + xa[i] * xb[i];
+#pragma unroll
+    for (int i = 860; i < 864; i++)
+      if (i + lane <= 863) dl = dl + xb[i] * xa[i];
+    acl = acl + dl;
+  }
+  float ac[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) ac[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acl), k));  // (the builtin moves ints)
+  ac[0] *= 1.0001f;
+#pragma unroll
+  for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+  float lpc[4] = {0, 0, 0, 0};
+  if (ac[0] != 0) {  // order-4 Levinson (src/celt_lpc.c:38-89), the same on every lane
+    float error = ac[0];
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (!done) {
+        float rr = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+        rr += ac[i + 1];
+        const float r = -rr / error;
+        lpc[i] = r;
+#pragma unroll
+        for (int j = 0; j < (i + 1) >> 1; j++) {
+          const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+          lpc[j] = t1 + r * t2;
+          lpc[i - 1 - j] = t2 + r * t1;
+        }
+        error = error - (r * r) * error;
+        if (error < .001f * ac[0]) done = true;
+      }
+    }
+  }
+  float tmp = 1.f;
+  const float c1 = .8f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    tmp = .9f * tmp;
+    lpc[i] = lpc[i] * tmp;
+  }
+  if (lane == 0) {
+    float *o = g.lpc2 + ((size_t)slot * g.n_stride + s) * 8;
+    o[0] = lpc[0] + .8f;
+    o[1] = lpc[1] + c1 * lpc[0];
+    o[2] = lpc[2] + c1 * lpc[1];
+    o[3] = lpc[3] + c1 * lpc[2];
+    o[4] = c1 * lpc[3];
+    if (RN_INSTRUMENT && g.debug) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
+    }
+  }
+}
+
+
+// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form: 64 streams = 64 waves for 13 us against one wave for 61)
+#define RN_HP_ONE_MAX 64
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
+  static const int one_max = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : RN_HP_ONE_MAX; }();  // (A/B runs)
+  if (g->n_streams <= one_max) {
+    RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16);
+    return hipGetLastError();
+  }
   RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot,
             1 | (in_s16 ? 2 : 0));
   return hipGetLastError();

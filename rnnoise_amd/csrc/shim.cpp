@@ -34,6 +34,7 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *, const RnTable
                                                const RnTrainArgs *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                           hipEvent_t);
+extern "C" hipError_t rn_launch_nn_one(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                         hipEvent_t);
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
@@ -512,7 +513,7 @@ int tables_for_device(int device, RnTablesDev &out) {
 
 struct DeviceModel {
   int device = -1;
-  void *mem = nullptr;
+  void *mem = nullptr, *mem_rows = nullptr;  // the staged model; the row-major int8 copies of the vector path
   RnModelDev dev{};
 };
 
@@ -764,6 +765,42 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
   RnLinearDev *dst[10] = {&d.dev.conv1, &d.dev.conv2, &d.dev.gru_in[0], &d.dev.gru_rec[0], &d.dev.gru_in[1], &d.dev.gru_rec[1],
                           &d.dev.gru_in[2], &d.dev.gru_rec[2], &d.dev.dense_out, &d.dev.vad_dense};
   for (int i = 0; i < 10; i++) *dst[i] = resolve_linear(base, sm.off[i], sm.lin[i]);
+  {  // row-major copies of the int8 layers (rn_dev.h: wrow / cq / grp4), derived from the staged block streams
+    Staging rows;
+    size_t o_w[10] = {}, o_c[10] = {}, o_g[10] = {};
+    for (int i = 1; i <= 7; i++) {
+      const DevLinearOffsets &o = sm.off[i];
+      const int nout = sm.lin[i].nout, ng = nout / 8;
+      const int8_t *w = reinterpret_cast<const int8_t *>(sm.st.bytes.data() + o.w);
+      const int32_t *grp = reinterpret_cast<const int32_t *>(sm.st.bytes.data() + o.grp);
+      const uint16_t *cols = reinterpret_cast<const uint16_t *>(sm.st.bytes.data() + o.cols);
+      std::vector<int32_t> g4(ng + 1, 0);
+      for (int g = 0; g < ng; g++) g4[g + 1] = g4[g] + (grp[g + 1] - grp[g] + 3) / 4;
+      std::vector<int32_t> wrow((size_t)g4[ng] * 8 * 4, 0);
+      std::vector<uint32_t> cq((size_t)g4[ng], 0);
+      for (int g = 0; g < ng; g++) {
+        const int nch = g4[g + 1] - g4[g], len = grp[g + 1] - grp[g];
+        for (int k = 0; k < len; k++) {
+          const int b = grp[g] + k;
+          const uint32_t col4 = o.has_cols ? cols[b] >> 2 : (uint32_t)k;
+          cq[g4[g] + k / 4] |= col4 << (8 * (k & 3));
+          for (int sub = 0; sub < 8; sub++)
+            memcpy(&wrow[((size_t)(g4[g] * 8 + sub * nch + k / 4)) * 4 + (k & 3)], w + (size_t)b * 32 + sub * 4, 4);
+        }
+      }
+      o_w[i] = rows.add(wrow.data(), 4 * wrow.size());
+      o_c[i] = rows.add(cq.data(), 4 * cq.size());
+      o_g[i] = rows.add(g4.data(), 4 * g4.size());
+    }
+    HIP_OK(hipMalloc(&d.mem_rows, rows.bytes.size()));
+    HIP_OK(hipMemcpy(d.mem_rows, rows.bytes.data(), rows.bytes.size(), hipMemcpyHostToDevice));
+    const uint8_t *rb = static_cast<const uint8_t *>(d.mem_rows);
+    for (int i = 1; i <= 7; i++) {
+      dst[i]->wrow = reinterpret_cast<const int *>(rb + o_w[i]);
+      dst[i]->cq = reinterpret_cast<const uint32_t *>(rb + o_c[i]);
+      dst[i]->grp4 = reinterpret_cast<const int *>(rb + o_g[i]);
+    }
+  }
   m->dev.push_back(d);
   out = d.dev;
   return 0;
@@ -782,6 +819,16 @@ int nn_layers_min_streams() {
   static const int v = [] {
     const char *e = getenv("RNNOISE_AMD_NN_LAYERS_MIN");
     return e ? atoi(e) : 16384;
+  }();
+  return v;
+}
+
+// Up to this many streams the vector-path network runs as the latency-oriented kernel (nn_kernels.hip: rn_nn_one_kernel, one
+// 7-wave workgroup with 114 KB of LDS per stream -- one per CU); $RNNOISE_AMD_NN_ONE_MAX overrides (A/B runs, 0 = never).
+int nn_one_max_streams() {
+  static const int v = [] {
+    const char *e = getenv("RNNOISE_AMD_NN_ONE_MAX");
+    return e ? atoi(e) : 256;
   }();
   return v;
 }
@@ -1157,6 +1204,7 @@ static int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void 
         TimedLaunch t(b, 1);
         b->img_valid = false;
         if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+        else if (g.n_streams <= nn_one_max_streams()) HIP_OK(rn_launch_nn_one(&g, &b->m, &b->tb, st, t.start(), t.stop()));
         else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
       }
     }
@@ -1817,7 +1865,8 @@ int pool_step(StatePool *p, int slot, int parity, int ring_slot, long frame_no, 
   const int prev = (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
   HIP_OK(rn_launch_hp(&g, d_in, 0, ring_slot, st, nullptr, nullptr));
   HIP_OK(rn_launch_analysis(&g, &b->tb, ring_slot, parity, st, nullptr, nullptr));
-  HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, nullptr, nullptr));
+  if (nn_one_max_streams() >= 1) HIP_OK(rn_launch_nn_one(&g, &b->m, &b->tb, st, nullptr, nullptr));
+  else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, nullptr, nullptr));
   HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out, 0, parity, prev, st, nullptr, nullptr));
   return 0;
 }
@@ -1838,6 +1887,7 @@ extern "C" void rnnoise_model_free(RNNModel *model) {
   for (auto &d : model->dev) {
     DeviceGuard guard(d.device);
     hipFree(d.mem);
+    hipFree(d.mem_rows);
   }
   if (model->file) fclose(model->file);
   delete model->staged;
