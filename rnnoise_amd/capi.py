@@ -203,7 +203,10 @@ class Model:
             self.h = None
 
     def __del__(self):
-        _close_quietly(self)
+        try:
+            _close_quietly(self)
+        except Exception:  # (at interpreter shutdown the helper itself may already be gone)
+            pass
 
 
 class Batch:
@@ -222,7 +225,10 @@ class Batch:
             self.h = None
 
     def __del__(self):
-        _close_quietly(self)
+        try:
+            _close_quietly(self)
+        except Exception:  # (at interpreter shutdown the helper itself may already be gone)
+            pass
 
     def reset(self):
         if lib().rnnoise_batch_reset(self.h):
@@ -355,4 +361,7 @@ class DenoiseState:
             self.h = None
 
     def __del__(self):
-        _close_quietly(self)
+        try:
+            _close_quietly(self)
+        except Exception:  # (at interpreter shutdown the helper itself may already be gone)
+            pass

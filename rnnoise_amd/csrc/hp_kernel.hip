@@ -354,8 +354,9 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int in_s1
 }
 
 
-// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form: 64 streams = 64 waves for 13 us against one wave for 61)
-#define RN_HP_ONE_MAX 64
+// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form -- measured K0 at 256 / 1024 / 2048 / 4096 streams: 24 / 26 / 35 / 66 us
+// against 55 / 55 / 55 / 59 us lane = stream: its 12.5 KB of LDS per wave limit a CU to 12 waves)
+#define RN_HP_ONE_MAX 3072
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
   static const int one_max = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : RN_HP_ONE_MAX; }();  // (A/B runs)
   if (g->n_streams <= one_max) {

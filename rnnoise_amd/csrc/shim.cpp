@@ -994,7 +994,10 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   b->model = model;
   b->device = device;
   b->n = n_streams;
-  b->nn_path = (n_streams >= 16 && rn_nn_mfma_available()) ? 1 : 0;  // same bits either way; MFMA tiles hold 16 streams
+  // same bits either way.  Up to 256 streams the latency-oriented vector kernel (one 7-wave workgroup per stream, each on a CU
+  // of its own) finishes first -- measured K2 at 16 / 64 / 256 streams: 58 / 58 / 78 us against 66 / 82 / 101 us for MFMA tiles
+  // of 16 streams; beyond that the MFMA paths do
+  b->nn_path = (n_streams > nn_one_max_streams() && n_streams >= 16 && rn_nn_mfma_available()) ? 1 : 0;
   if (model_on_device(model, device, b->m) || tables_for_device(device, b->tb)) {
     delete b;
     return nullptr;
@@ -1980,19 +1983,29 @@ extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float
   if (!st || (st->magic != kStateMagic && st->magic != kPooledMagic) || !st->model || !out || !in)
     return frame_failed(out, "uninitialised state or NULL buffer");
   if (st->magic == kPooledMagic) {
-    // device-resident state: 1,920 bytes up, four launches on the state's own stream, 1,924 bytes (frame + VAD) down
+    // device-resident state: four launches on the state's own stream
     PooledRef &r = st->ref;
     std::lock_guard<std::mutex> lk(*r.mu);
     DeviceGuard guard(r.pool->batch->device);
     if (!guard.ok) return frame_failed(out, "cannot select the HIP device");
-    float *d_in = r.pool->d_io + (size_t)r.slot * 2 * 484, *d_out = d_in + 484;
+    // The frame travels through the state's pinned block, which the kernels address directly (host memory mapped into the
+    // device's address space: the first kernel reads its 1,920 bytes over PCIe, the last ones write frame and VAD back): no
+    // copy commands, four launches and one wait per frame.  $RNNOISE_AMD_POOL_IO=copy stages through HBM instead (A/B runs).
+    static const bool zero_copy = [] { const char *e = getenv("RNNOISE_AMD_POOL_IO"); return !e || strcmp(e, "copy"); }();
     float *h_in = r.h_io, *h_out = r.h_io + 484;
     memcpy(h_in, in, RN_FRAME_SIZE * sizeof(float));
-    if (hipMemcpyAsync(d_in, h_in, RN_FRAME_SIZE * sizeof(float), hipMemcpyHostToDevice, r.stream) != hipSuccess ||
-        pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, d_out, d_in, d_out + RN_FRAME_SIZE, r.stream) ||
-        hipMemcpyAsync(h_out, d_out, (RN_FRAME_SIZE + 1) * sizeof(float), hipMemcpyDeviceToHost, r.stream) != hipSuccess ||
-        hipStreamSynchronize(r.stream) != hipSuccess)
-      return frame_failed(out, "GPU step failed");
+    bool ok;
+    if (zero_copy) {
+      ok = pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, h_out, h_in, h_out + RN_FRAME_SIZE, r.stream) == 0 &&
+           hipStreamSynchronize(r.stream) == hipSuccess;
+    } else {
+      float *d_in = r.pool->d_io + (size_t)r.slot * 2 * 484, *d_out = d_in + 484;
+      ok = hipMemcpyAsync(d_in, h_in, RN_FRAME_SIZE * sizeof(float), hipMemcpyHostToDevice, r.stream) == hipSuccess &&
+           pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, d_out, d_in, d_out + RN_FRAME_SIZE, r.stream) == 0 &&
+           hipMemcpyAsync(h_out, d_out, (RN_FRAME_SIZE + 1) * sizeof(float), hipMemcpyDeviceToHost, r.stream) == hipSuccess &&
+           hipStreamSynchronize(r.stream) == hipSuccess;
+    }
+    if (!ok) return frame_failed(out, "GPU step failed");
     r.parity = (r.parity + 1) % RN_SPEC_SLOTS;
     r.ring_slot = (r.ring_slot + 1) % RN_RING_SLOTS;
     r.frame_no++;

@@ -489,7 +489,7 @@ def test_mfma_path_bit_exact(model, blob_default, n, path):
     pcm[20:26, 1::4] = 0      # others go silent mid-way (state must freeze, src/denoise.c:474)
     uniq = sorted({(i, s % 3 == 0, s % 4 == 1) for s, i in enumerate(ids)})
     b = capi.Batch(model, n)
-    assert b.set_nn_path(path) == (1 if n >= 16 else 0)   # documented default: MFMA from one full tile up
+    assert b.set_nn_path(path) == (1 if n > 256 else 0)   # documented default: up to 256 streams the latency-oriented vector kernel
     out, vad, gains = b.process(pcm)
     cache = {}
     for s, i in enumerate(ids):

@@ -17,8 +17,11 @@ from rnnoise_amd import capi  # noqa: E402
 
 dev = torch.device("cuda:0")
 model = capi.Model(bench.load_blob())
-for N in [int(x) for x in sys.argv[1:]] or [4096, 65536]:
+vector = "--vector" in sys.argv  # the vector-path network (rn_nn_one_kernel up to 256 streams) instead of the batch default
+for N in [int(x) for x in sys.argv[1:] if not x.startswith("-")] or [4096, 65536]:
     b = capi.Batch(model, N)
+    if vector:
+        b.set_nn_path(0)
     cap = 8
     d_in = bench.synth_pcm_torch(torch, N, cap, dev, seed_base=0)
     d_out = torch.empty_like(d_in)
