@@ -79,15 +79,17 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
     three of the five and the longest."""
     if kind == "network":
         if nn != "mfma":
-            return "rn_nn_vector_kernel"
+            return "rn_nn_one_kernel" if n_streams <= 256 else "rn_nn_vector_kernel"  # shim.cpp: nn_one_max_streams()
         return "rn_nn_gru_kernel" if n_streams >= NN_LAYERS_MIN_STREAMS else "rn_nn_mfma_kernel"
     if kind == "analysis" and n_streams < 6144:
         return "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
+    if kind == "highpass" and n_streams <= 3072:
+        return "rn_hp_one_kernel"           # one wave per stream up to RN_HP_ONE_MAX (hp_kernel.hip)
     return KERNEL_OF[kind]
 
 
 def waves_per_launch(kind: str, n_streams: int) -> int:
-    return {"highpass": -(-n_streams // 64), "analysis": -(-n_streams // 4) * 4 if n_streams >= 6144 else n_streams,
+    return {"highpass": n_streams if n_streams <= 3072 else -(-n_streams // 64), "analysis": -(-n_streams // 4) * 4 if n_streams >= 6144 else n_streams,
             "network": (-(-n_streams // 64) if n_streams >= NN_LAYERS_MIN_STREAMS else -(-n_streams // 16)) * 8,
             "synthesis": n_streams}[kind]
 

@@ -7,32 +7,42 @@ torch is plumbing here (HBM buffers, streams); the arithmetic runs in librnnoise
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 
 from . import blob as rblob
 from . import capi
 
 
-_OPS = {}          # handle -> RNNoiseOp: what torch.ops.rnnoise_amd.process resolves its integer argument to
+# handle -> RNNoiseOp: what torch.ops.rnnoise_amd.process resolves its integer argument to.  Weak: an op nobody holds any
+# more is closed by its destructor (it owns a GPU arena and a model), not kept alive by this table.
+_OPS = weakref.WeakValueDictionary()
 _registered = False
 
 
 def register_torch_op():
-    """Registers `torch.ops.rnnoise_amd.process(pcm, handle) -> (out, vad, gains)` (torch.library custom op, forward only).
-    `handle` is RNNoiseOp.handle: the op is stateful per stream batch, like the C API it binds, and the state lives in the
-    library, not in tensors.  A fake (meta) implementation gives shapes to tracing / torch.compile."""
+    """Registers `torch.ops.rnnoise_amd.process(pcm, state, handle) -> (out, vad, gains)` (torch.library custom op, forward
+    only).  `handle` is RNNoiseOp.handle: the op is stateful per stream batch, like the C API it binds, and the stream state
+    lives in the library, not in tensors.  So that tracing / functionalization / torch.compile cannot treat it as a pure
+    function -- merge two calls with the same arguments, or drop one whose outputs are unused, and silently desynchronise the
+    streams -- the op MUTATES its `state` argument (RNNoiseOp.state: the batch's frame counter, a one-element int64 tensor,
+    advanced by the number of frames of every call).  A fake (meta) implementation gives shapes."""
     global _registered
     if _registered:
         return
     import torch
 
     # (explicit schema: this module uses postponed annotations, which infer_schema cannot resolve for a local import)
-    @torch.library.custom_op("rnnoise_amd::process", mutates_args=(), schema="(Tensor pcm, int handle) -> (Tensor, Tensor, Tensor)")
-    def process(pcm, handle):
-        return _OPS[handle]._run(pcm)
+    @torch.library.custom_op("rnnoise_amd::process", mutates_args=("state",),
+                             schema="(Tensor pcm, Tensor(a!) state, int handle) -> (Tensor, Tensor, Tensor)")
+    def process(pcm, state, handle):
+        res = _OPS[handle]._run(pcm)
+        state.add_(pcm.shape[0])
+        return res
 
     @process.register_fake
-    def _(pcm, handle):
+    def _(pcm, state, handle):
         T, N = pcm.shape[0], pcm.shape[1]
         return torch.empty_like(pcm), pcm.new_empty((T, N)), pcm.new_empty((T, N, capi.NB_BANDS))
 
@@ -41,7 +51,7 @@ def register_torch_op():
 
 class RNNoiseOp:
     """N concurrent streams; call with a (T, N, 480) float32 CUDA tensor of int16-scaled PCM.  The same object is
-    reachable as the registered op: torch.ops.rnnoise_amd.process(pcm, op.handle)."""
+    reachable as the registered op: torch.ops.rnnoise_amd.process(pcm, op.state, op.handle)."""
 
     def __init__(self, model_blob: bytes, n_streams: int, device: int = 0, nn_path: str = "mfma"):
         import torch
@@ -54,15 +64,24 @@ class RNNoiseOp:
         self.n = n_streams
         register_torch_op()
         self.handle = id(self)
+        self.state = torch.zeros(1, dtype=torch.int64, device=self.device)  # frames processed: the tensor the op mutates
         _OPS[self.handle] = self
 
     def close(self):
-        _OPS.pop(self.handle, None)
-        self.batch.close()
-        self.model.close()
+        _OPS.pop(getattr(self, "handle", None), None)
+        if getattr(self, "batch", None) is not None:
+            self.batch.close()
+            self.model.close()
+            self.batch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __call__(self, pcm):
-        return self.torch.ops.rnnoise_amd.process(pcm, self.handle)
+        return self.torch.ops.rnnoise_amd.process(pcm, self.state, self.handle)
 
     def _run(self, pcm):
         torch = self.torch
@@ -78,6 +97,7 @@ class RNNoiseOp:
 
     def reset(self):
         self.batch.reset()
+        self.state.zero_()
 
 
 class FloatNet:

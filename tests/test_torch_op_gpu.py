@@ -89,8 +89,9 @@ def test_registered_op_and_reference_torch_cross_check():
     pcm = synth.batch_pcm(ids, T)
     op = RNNoiseOp(blob, len(ids))
     x = torch.from_numpy(pcm).cuda()
-    out, vad, gains = torch.ops.rnnoise_amd.process(x, op.handle)
+    out, vad, gains = torch.ops.rnnoise_amd.process(x, op.state, op.handle)
     torch.cuda.synchronize()
+    assert int(op.state.item()) == T      # the tensor the op mutates (what keeps tracing from treating it as a pure function)
     gains, vad = gains.cpu().numpy(), vad.cpu().numpy()
     d = np.abs(gains[SETTLE:, 0] - g["gains"][SETTLE - 4:])
     assert d.max() < TOL_MAX and d.mean() < TOL_MEAN, (d.max(), d.mean())
@@ -101,7 +102,8 @@ def test_registered_op_and_reference_torch_cross_check():
     assert_bits_equal(out[:, 17].cpu().numpy(), Oracle(blob).run(pcm[:, 17])["out"], "pcm of the ragged tile")
     # the fake (meta) kernel gives shapes without running anything
     with torch._subclasses.fake_tensor.FakeTensorMode():
-        fo, fv, fg = torch.ops.rnnoise_amd.process(torch.empty((3, len(ids), 480), device="cuda"), op.handle)
+        fo, fv, fg = torch.ops.rnnoise_amd.process(torch.empty((3, len(ids), 480), device="cuda"),
+                                                   torch.zeros(1, dtype=torch.int64, device="cuda"), op.handle)
         assert fo.shape == (3, len(ids), 480) and fv.shape == (3, len(ids)) and fg.shape == (3, len(ids), 32)
     op.close()
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun): produces every artefact kept under profiles/ into gpurun_out/prof/.
-#   tools/collect_profiles.sh   -> bench lines (configs[1..3] + host-fed), rocprofv3 kernel stats, PMC passes, section taps
+#   tools/collect_profiles.sh   -> bench lines (configs[1..3], host-fed float / int16, one frame per call), rocprofv3 kernel stats,
+#                                  PMC passes, section taps, the VALU issue table and the PCIe yardstick
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof
@@ -13,8 +14,14 @@ python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 > "
 python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 --nn vector > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_4096_vector.json"
 python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 > "$O/b.log" 2>&1;                 last "$O/b.log" > "$O/bench_little_32768.json"
 python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 > "$O/b.log" 2>&1;          last "$O/b.log" > "$O/bench_16384.json"
-python "$R/bench.py" --no-cpu-baseline --host-io --steps 8 --warmup 2 --repeats 9 > "$O/b.log" 2>&1;     last "$O/b.log" > "$O/bench_hostio_65536.json"
-python "$R/tools/serial_times.py" 4096 16384 65536 2>&1 | grep "N=" > "$O/serial_times.txt"
+python "$R/bench.py" --no-cpu-baseline --host-io --steps 12 --warmup 4 --repeats 7 > "$O/b.log" 2>&1;    last "$O/b.log" > "$O/bench_hostio_65536.json"
+python "$R/bench.py" --no-cpu-baseline --host-io --s16 --steps 16 --warmup 4 --repeats 7 > "$O/b.log" 2>&1; last "$O/b.log" > "$O/bench_hostio_s16_65536.json"
+python "$R/bench.py" --no-cpu-baseline --s16 > "$O/b.log" 2>&1;                                            last "$O/b.log" > "$O/bench_s16_65536.json"
+python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 --frames-per-call 1 > "$O/b.log" 2>&1;  last "$O/b.log" > "$O/bench_4096_fpc1.json"
+python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 --frames-per-call 1 > "$O/b.log" 2>&1;  last "$O/b.log" > "$O/bench_16384_fpc1.json"
+python "$R/tools/pcie_peak.py" 2>&1 | grep pinned > "$O/pcie_peak.txt"
+python "$R/tools/serial_times.py" 1 64 1024 4096 16384 65536 2>&1 | grep "N=" > "$O/serial_times.txt"
+timeout 600 "$R/rnnoise_amd/csrc/build/valu_issue" > "$O/valu_issue.txt" 2>&1
 RNNOISE_AMD_NN_LAYERS_MIN=100000000 python "$R/tools/ab_layers.py" 65536 2>&1 | grep -E "^N=|^n=" > "$O/network_schedules_65536.txt"
 python "$R/tools/k1_cycles.py" 65536 --nn --layers 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
 python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"

@@ -11,12 +11,13 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-pre = sys.argv[3] if len(sys.argv) > 3 else "r2"
+pre = sys.argv[3] if len(sys.argv) > 3 else "r3"
 
-for n in ("bench_65536", "bench_4096", "bench_4096_vector", "bench_16384", "bench_little_32768", "bench_hostio_65536"):
+for n in ("bench_65536", "bench_4096", "bench_4096_vector", "bench_16384", "bench_little_32768", "bench_hostio_65536",
+          "bench_hostio_s16_65536", "bench_s16_65536", "bench_4096_fpc1", "bench_16384_fpc1"):
     if os.path.exists(os.path.join(src, n + ".json")) and os.path.getsize(os.path.join(src, n + ".json")) > 10:
         shutil.copy(os.path.join(src, n + ".json"), os.path.join(dst, f"{pre}_{n}.json"))
-for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench", "network_schedules_65536"):
+for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench", "network_schedules_65536", "pcie_peak", "valu_issue"):
     if os.path.exists(os.path.join(src, n + ".txt")):
         shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
