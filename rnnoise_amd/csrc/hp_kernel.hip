@@ -188,7 +188,7 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
 // biquad recurrence runs once per wave (every lane computes the same values from broadcast LDS reads), each autocorrelation
 // lag is one lane's chain in the reference's order -- but the five lags run side by side on lanes 0-4 instead of one after
 // the other in a lane, the 2x decimation is spread over the wave, and global memory is touched in coalesced rows only
-// (frame and pitch_buf come in through LDS).  43 us -> about 13 us for one stream.
+// (frame and pitch_buf come in through LDS).  43 us -> 22 us for one stream (the biquad chain alone is ~8 us).
 // ---------------------------------------------------------------------------------------------
 struct HpOneLds {
   float pb[RN_PITCH_BUF_SIZE];  // pitch_buf of this frame: 1248 old samples from the ring, then the 480 just filtered

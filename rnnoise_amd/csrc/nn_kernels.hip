@@ -9,6 +9,7 @@
 
 #define NN_THREADS 384
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 // ---- x86-profile activations (src/vec_avx.h:398-445) with the captured rcpps table ----
 __device__ __forceinline__ float rcp_x86(float x, const uint16_t *__restrict__ lut) { return rn_rcp_x86(x, lut); }
@@ -73,53 +74,87 @@ __device__ __forceinline__ float int8_row(const RnLinearDev &l, int row, const i
   return (float)acc * l.scale[row] + l.bias[row];
 }
 
-// NR output rows of int8 layers at once -- float(acc_x86) * scale + subias (src/vec_avx.h:778-877, src/nnet_arch.h:145-151).
-// (the latency-oriented kernel below; the throughput kernel keeps int8_row: with two workgroups per CU its one-load-at-a-time
-// rows overlap each other, and the byte extraction here costs it more issue slots than the wide loads save: 3.6 M against
-// 4.5 M frames/s at 4096 streams.)  Row r comes from layer l[r] with the quantised input xq[r].  The accumulator is an integer, so the order of its terms is
-// free: a row's blocks are read from the row-major copy (rn_dev.h: wrow / cq / grp4) four per 16-byte load, U chunks of all NR
-// rows requested before the first dot product is issued.  (Thread = row with one block per 4-byte load and one load in
-// flight took 107 us for one stream's network: first the L2 round trip per block, then -- with the loads batched -- the
-// texture addresser, which spends as long on a 4-byte load as on a 16-byte one.)  Chunks past a row's end are clamped to its
-// last chunk and enter with weight 0; padding blocks inside the last chunk are zero in the copy.
+// NR integer row products of int8 layers at once (the latency-oriented kernel below; the throughput kernel keeps int8_row:
+// with two workgroups per CU its one-load-at-a-time rows overlap each other, and the byte extraction here costs it more issue
+// slots than the wide loads save: 3.6 M against 4.5 M frames/s at 4096 streams).  Row r comes from layer l[r] with the quantised
+// input xq[r]; acc[r] = sum over the row's blocks of w . x (add rowsum128, scale and bias with int8_finish).  The accumulator
+// is an integer, so the order of its terms is free: a row's blocks are read from the row-major copy (rn_dev.h: wrow / cq /
+// grp4) four per 16-byte load, U chunks of all NR rows requested before the first dot product is issued, and a row may be
+// split between `nparts` threads (part p takes chunks [nch p / nparts, nch (p + 1) / nparts)).  Thread = row with one block
+// per 4-byte load and one load in flight took 107 us for one stream's network: first the L2 round trip per block, then --
+// with the loads batched -- the texture addresser, which spends as long on a 4-byte load as on a 16-byte one.
+// Chunks past the range are clamped to its last chunk and dropped; padding blocks inside a group's last chunk are zero.
+struct RowSrc {  // where a thread's rows come from: the row-major copy of one int8 layer + its epilogue vectors
+  const int *grp4, *wrow, *rowsum128;
+  const uint32_t *cq;
+  const float *scale, *bias, *diag;
+};
+__device__ __forceinline__ RowSrc row_src(const RnLinearDev &l) { return RowSrc{l.grp4, l.wrow, l.rowsum128, l.cq, l.scale, l.bias, l.diag}; }
+// (field-wise select: the layer structs live in kernel-argument memory, their fields arrive by scalar loads; selecting the
+//  STRUCT per lane would turn every field access into a vector load from that memory)
+__device__ __forceinline__ RowSrc row_src_select(bool second, const RnLinearDev &a, const RnLinearDev &b) {
+  return RowSrc{second ? b.grp4 : a.grp4, second ? b.wrow : a.wrow, second ? b.rowsum128 : a.rowsum128, second ? b.cq : a.cq,
+                second ? b.scale : a.scale, second ? b.bias : a.bias, second ? b.diag : a.diag};
+}
+// g0[r], g1[r] = grp4[row >> 3], grp4[(row >> 3) + 1], fetched by the caller AHEAD of the phase (with the epilogue vectors:
+// every dependent global round trip costs one stream's network 1.5-2 us, and a GRU layer had eight of them in series --
+// group bounds, weights, row sums / scales / biases, diagonal, three table lookups of the activations)
+// The four lanes of a quad hold four rows of ONE 8-row group (callers map threads that way), so they walk the same chunks and
+// need the same four activation dwords per chunk: each lane reads ONE of them from LDS (the block lane & 3 of the chunk) and
+// the quad shares them by DPP broadcast -- a quarter of the LDS instructions.  (With one read per block the row waves kept
+// the CU's LDS pipe busy for ~10 k cycles per GRU layer, and the dense_out / vad chains on their own waves, which live on
+// LDS operands, crawled behind them: 32 k cycles per layer, THE critical path.)
+template <int J>
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
 template <int NR, int U>
-__device__ __forceinline__ void int8_rows(const RnLinearDev *const (&l)[NR], const int (&row)[NR], const int *const (&xq)[NR], float (&out)[NR]) {
-  int nch[NR], acc[NR], maxn = 0;
+__device__ __forceinline__ void int8_rows(const RowSrc &l, const int (&row)[NR], const int (&g0a)[NR], const int (&g1a)[NR], const int *xq,
+                                          int part, int nparts, int (&acc)[NR]) {
+  int n[NR], maxn = 0;
   const v4i_t *wr[NR];
   const uint32_t *cq[NR];
+  const int qsh = 8 * (threadIdx.x & 3);
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    const int grp = row[r] >> 3, g0 = l[r]->grp4[grp];
-    nch[r] = l[r]->grp4[grp + 1] - g0;
-    wr[r] = reinterpret_cast<const v4i_t *>(l[r]->wrow) + (g0 * 8 + (row[r] & 7) * nch[r]);
-    cq[r] = l[r]->cq + g0;
-    maxn = max(maxn, nch[r]);
+    const int g0 = g0a[r], nch = g1a[r] - g0;
+    const int lo = nch * part / nparts, hi = nch * (part + 1) / nparts;
+    n[r] = hi - lo;
+    wr[r] = reinterpret_cast<const v4i_t *>(l.wrow) + ((g0 + lo) * 8 + (row[r] & 7));
+    cq[r] = l.cq + g0 + lo;
+    maxn = max(maxn, n[r]);
     acc[r] = 0;
   }
-  for (int i = 0; i < maxn; i += U) {
+  for (int i = 0; i < maxn; i += U) {  // (uniform within a quad: its four lanes share their groups)
     v4i_t w[NR][U];
     uint32_t c[NR][U];
+    int x[NR][U];
 #pragma unroll
     for (int r = 0; r < NR; r++)
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int k = max(min(i + u, nch[r] - 1), 0);
-        w[r][u] = wr[r][k];
+        const int k = max(min(i + u, n[r] - 1), 0);
+        w[r][u] = wr[r][k * 8];
         c[r][u] = cq[r][k];
       }
 #pragma unroll
     for (int r = 0; r < NR; r++)
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const bool ok = i + u < nch[r];
+      for (int u = 0; u < U; u++) x[r][u] = xq[(c[r][u] >> qsh) & 0xff];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[r] = __builtin_amdgcn_sdot4(ok ? w[r][u][j] : 0, xq[r][(c[r][u] >> (8 * j)) & 0xff], acc[r], false);
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int t4 = __builtin_amdgcn_sdot4(w[r][u][0], quad_bcast<0>(x[r][u]), 0, false);
+        t4 = __builtin_amdgcn_sdot4(w[r][u][1], quad_bcast<1>(x[r][u]), t4, false);
+        t4 = __builtin_amdgcn_sdot4(w[r][u][2], quad_bcast<2>(x[r][u]), t4, false);
+        t4 = __builtin_amdgcn_sdot4(w[r][u][3], quad_bcast<3>(x[r][u]), t4, false);
+        acc[r] += (i + u < n[r]) ? t4 : 0;
       }
   }
-#pragma unroll
-  for (int r = 0; r < NR; r++) out[r] = (float)(acc[r] + l[r]->rowsum128[row[r]]) * l[r]->scale[row[r]] + l[r]->bias[row[r]];
 }
+// float(acc_x86) * scale + subias (src/vec_avx.h:778-877, src/nnet_arch.h:145-151), the three vectors prefetched
+struct RowEpi { int rowsum; float scale, bias; };
+__device__ __forceinline__ RowEpi row_epi(const RowSrc &l, int row) { return RowEpi{l.rowsum128[row], l.scale[row], l.bias[row]}; }
+__device__ __forceinline__ float int8_finish(const RowEpi &e, int acc) { return (float)(acc + e.rowsum) * e.scale + e.bias; }
 
 struct NnLds {
   float tmp1[196];  // conv1 input  [t-2 | t-1 | t]   (src/nnet.c:118-119)
@@ -210,20 +245,30 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *g, const RnModelDev 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 for a handful of streams (the one-stream states behind rnnoise_process_frame, include/rnnoise.h:94): the same network
-// and the same bits as rn_nn_vector_kernel, arranged for LATENCY.  One workgroup of 7 waves per stream:
-//   * waves 0-5 (thread = output row / hidden unit) run conv1 -> conv2 -> GRU x 3 with the prefetched row products above;
-//   * wave 6 runs the two 1536-step chains of dense_out / vad_dense (serial by definition: one fmaf -- resp. mul + add -- per
-//     input, in input order) BESIDE the GRU layers: the chain over cat segment s (conv2 output, then each GRU's new state)
-//     runs while the next GRU layer is computed, so only the last 384 steps are exposed;
+// K2 for a handful of streams (the one-stream states behind rnnoise_process_frame, include/rnnoise.h:94, and batches of up to
+// 256 streams): the same network and the same bits as rn_nn_vector_kernel, arranged for LATENCY.  One workgroup of 14 waves
+// per stream:
+//   * waves 0-5: thread u = the three input-matrix rows of hidden unit u (and conv2's row u, and the unit's gates); waves 6-11:
+//     thread u = the three recurrent rows (+ diagonal), handed to the gate thread through LDS.  Row products come from the
+//     row-major int8 copy, four blocks per 16-byte load; a quad's four lanes are four rows of one group and share their
+//     activation reads; what a layer needs besides weights (old state, group bounds, row sums / scales / biases, diagonal)
+//     is requested one layer ahead; the rcpps table of the activations lives in LDS;
+//   * wave 12 runs the 32 dense_out chains, wave 13 the vad_dense chain (serial by definition: one fmaf -- resp. mul + add --
+//     per input, in input order) BESIDE the GRU layers: the chain over cat segment s (conv2 output, then each GRU's new state)
+//     runs while the next GRU layer is computed, so only the last 384 steps are exposed; operands sixteen steps at a time,
+//     the next sixteen in flight;
 //   * every float weight a chain touches is in LDS before the chain needs it, brought there by LDS-DMA (no registers, no
 //     instruction waits for it until its consumer does): conv1's 195 x 128 matrix by all waves at the start, vad_dense's 1536
-//     weights and dense_out's 384 x 32 segments by wave 6, two segments ahead of their chain (two 48 KB buffers that take
-//     over conv1's space).  A chain step is then an LDS read and an FMA, not an L2 round trip.
+//     weights by wave 13, dense_out's 384 x 32 segments by wave 12, two segments ahead of their chain (two 48 KB buffers that
+//     take over conv1's space).  A chain step is then an LDS read and an FMA, not an L2 round trip.
+// 107 us (thread = row, one 4-byte load in flight) -> 40 us for one stream; where the time went is in DESIGN.md section 9.
 // ---------------------------------------------------------------------------------------------
-#define ONE_THREADS 448
+#define ONE_ROW_THREADS 768   // 12 waves of row threads
+#define ONE_THREADS 896       // + wave 12: the dense_out chains (lane = output), wave 13: the vad chain
 struct OneLds {
   NnLds n;
+  uint16_t lut[4096];  // rcpps table (rn_dev.h: rcp16)
+  float ex[3][RN_GRU];  // a layer's recurrent sums (z, r, h rows), handed from the recurrent-row threads to the gate threads
   float vadw[RN_CAT];
   float big[25088];  // conv1 weights (24,960 floats, 98 DMA pieces) at the start; then two buffers of 384 x 32 dense_out weights
 };
@@ -241,6 +286,9 @@ __device__ __forceinline__ void one_dma_1k(const void *gsrc, unsigned lds_dst) {
 __device__ __forceinline__ unsigned one_lds_addr(const void *p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
+// the value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ int one_pair_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ float one_pair_f(float v) { return __int_as_float(one_pair_i(__float_as_int(v))); }
 
 extern "C" __global__ void __launch_bounds__(ONE_THREADS)
 rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
@@ -248,9 +296,13 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   OneLds &O = *reinterpret_cast<OneLds *>(one_smem);
   NnLds &L = O.n;
   const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool chain_wave = t >= RN_GRU;           // wave 6
-  const int ct = t - RN_GRU;                     // its lane: 0..31 dense_out outputs, 32 the vad chain
-  const uint16_t *lut = tb.rcp16;
+  const bool chain_wave = t >= ONE_ROW_THREADS;  // waves 12 (dense_out) and 13 (vad_dense)
+  const bool vad_wave = wave == 13;
+  const int ct = lane & 31;                      // wave 12: dense_out output of this lane (the upper half repeats the lower)
+  // row threads: waves 0-5 the rows of the input matrices (and conv2), waves 6-11 those of the recurrent matrices; a quad = four
+  // consecutive rows of one 8-row group (int8_rows shares their activation reads)
+  const int half = t >= RN_GRU && t < ONE_ROW_THREADS, u = t - (t >= RN_GRU ? RN_GRU : 0);
+  const uint16_t *lut = O.lut;  // the rcpps table in LDS: three dependent lookups per unit and layer must not be L2 trips
   if (g.silence[s]) {  // src/denoise.c:474
     if (t < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + t] = 0;
     if (t == 0) g.vad[s] = 0;
@@ -258,19 +310,30 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   }
   float *c1s = g.conv1_state + (size_t)s * 130;
   float *c2s = g.conv2_state + (size_t)s * 256;
-  {  // conv1 weights -> LDS: 98 pieces of 1 KB, 14 per wave (the last piece's tail lanes re-read the last 16 bytes)
+  // (instrumented build: shader-clock taps of thread 0 -> slots RN_DBG_CLK2 + 0..7, of the chain wave -> + 8..13; tools/nn_one_taps.py)
+#if RN_INSTRUMENT
+  float *dbg = (g.debug && (t == 0 || t == ONE_ROW_THREADS)) ? g.debug + (size_t)s * RN_DBG_FLOATS + RN_DBG_CLK2 + (t ? 8 : 0) : nullptr;
+  unsigned long long clk_prev = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+  int tap_i = 0;
+#define ONE_TAP() do { if (g.debug) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (dbg && tap_i < 8 - (t ? 2 : 0)) dbg[tap_i] = (float)(now_ - clk_prev); tap_i++; clk_prev = now_; } } while (0)
+#else
+#define ONE_TAP() do { } while (0)
+#endif
+  {  // conv1 weights -> LDS: 98 pieces of 1 KB over 13 waves (the last piece's tail lanes re-read the last 16 bytes)
     const char *src = reinterpret_cast<const char *>(m.conv1.fw);
     const unsigned dst = one_lds_addr(O.big);
     constexpr int last = RN_CONV1_K * 128 * 4 - 16;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-      const int piece = wave + 7 * i;
+    for (int i = 0; i < 7; i++) {
+      const int piece = wave + 14 * i;  // wave-uniform; 14 x 7 = 98
       one_dma_1k(src + min(piece * 1024 + lane * 16, last), dst + piece * 1024);
     }
-    if (chain_wave) {
+    if (vad_wave) {
 #pragma unroll
       for (int i = 0; i < RN_CAT * 4 / 1024; i++)
         one_dma_1k(reinterpret_cast<const char *>(m.vad_dense.fw) + i * 1024 + lane * 16, one_lds_addr(O.vadw) + i * 1024);
+    } else if (wave < 8) {
+      one_dma_1k(reinterpret_cast<const char *>(tb.rcp16) + wave * 1024 + lane * 16, one_lds_addr(O.lut) + wave * 1024);
     }
     if (t < 130) L.tmp1[t] = c1s[t];
     if (t < 65) L.tmp1[130 + t] = g.features[(size_t)s * 68 + t];
@@ -278,100 +341,165 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  ONE_TAP();  // 0: weights of conv1 and the inputs are in LDS
+  // (conv2's group bounds and epilogue vectors start their trip now: consumed two barriers later)
+  const RowSrc c2 = row_src(m.conv2);
+  const bool c2_thread = t < RN_GRU;  // (conv2: one thread per row; the recurrent-row waves sit it out)
+  const int c2g0 = c2_thread ? c2.grp4[u >> 3] : 0, c2g1 = c2_thread ? c2.grp4[(u >> 3) + 1] : 0;
+  const RowEpi c2e = c2_thread ? row_epi(c2, u) : RowEpi{0, 0.f, 0.f};
   // conv1: float, 195 -> 128, one FMA chain per output (src/vec_avx.h:672-730), tanh
   if (t < 128) {
+    const float b1 = m.conv1.bias[t];
     float acc = 0;
-#pragma unroll 15
+#pragma unroll 39
     for (int j = 0; j < RN_CONV1_K; j++) acc = fmaf(O.big[j * 128 + t], L.tmp1[j], acc);
-    const float v = tanh_x86(acc + m.conv1.bias[t], lut);
+    const float v = tanh_x86(acc + b1, lut);
     L.c1[t] = v;
     L.tmp2[256 + t] = v;
   }
   if (t >= 192 && t < 192 + 130) c1s[t - 192] = L.tmp1[65 + t - 192];  // history <- last two frames
   __syncthreads();  // (conv1's weights have been consumed: both dense_out buffers are free)
+  ONE_TAP();  // 1: conv1
   if (t < 96) L.xq[t] = pack4(L.tmp2 + 4 * t);
   if (t >= 128 && t < RN_GRU) c2s[t - 128] = L.tmp2[t];  // conv2 history <- tmp2[128..383]
-  // dense_out weights of cat segment `seg` (384 x 32 floats, contiguous, 48 pieces) -> LDS buffer seg & 1, by wave 6
+  // dense_out weights of cat segment `seg` (384 x 32 floats, contiguous, 48 pieces) -> LDS buffer seg & 1, by the chain wave
   auto fetch_segment = [&](int seg) {
     const char *src = reinterpret_cast<const char *>(m.dense_out.fw) + (size_t)seg * 49152 + lane * 16;
     const unsigned dst = one_lds_addr(O.big) + (seg & 1) * 49152;
 #pragma unroll
     for (int i = 0; i < 48; i++) one_dma_1k(src + i * 1024, dst + i * 1024);
   };
-  // the chains of wave 6 over one segment
-  float dacc = 0, vacc = 0;
-  auto chain_segment = [&](int seg) {
-    const float *w = O.big + (seg & 1) * 12288, *x = L.cat + seg * RN_GRU, *vw = O.vadw + seg * RN_GRU;
-    if (ct < RN_NB_BANDS) {
-#pragma unroll 16
-      for (int j = 0; j < RN_GRU; j++) dacc = fmaf(w[j * RN_NB_BANDS + ct], x[j], dacc);
-    } else if (ct == RN_NB_BANDS) {  // the scalar tail of sgemv (src/vec_avx.h:732-736): unfused mul + add
-#pragma unroll 16
-      for (int j = 0; j < RN_GRU; j++) vacc = vacc + vw[j] * x[j];
+  // The chains over one segment of cat, 384 steps each, wave-uniform code (wave 12: lanes = the 32 dense_out outputs, one
+  // fmaf per step; wave 13: every lane the same vad chain, the scalar tail of sgemv, src/vec_avx.h:732-736: unfused mul + add).
+  // Operands come from LDS sixteen steps at a time, the next sixteen requested before the current ones are consumed: left to
+  // the compiler every step waited out its own LDS round trip (48 cycles x 768 steps per layer -- THE critical path of the
+  // first version, longer than the GRU rows beside it).
+  float cacc = 0;
+  // (two copies of the loop behind a wave-uniform branch: with the mul + add / fmaf choice INSIDE the loop the compiler computed
+  //  both and selected per step -- a v_cndmask on VCC in the dependency chain, 16-19 clocks each: 73 cycles per step)
+  auto chain_steps = [&](const float *w, int ws, const float *x, auto step) {
+    float wa[16], wb[16];
+    v4f_t xa[4], xb[4];
+    auto fetch = [&](float (&wv)[16], v4f_t (&xv)[4], int b) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) wv[i] = w[(16 * b + i) * ws];
+#pragma unroll
+      for (int i = 0; i < 4; i++) xv[i] = *reinterpret_cast<const v4f_t *>(x + 16 * b + 4 * i);
+    };
+    auto run = [&](const float (&wv)[16], const v4f_t (&xv)[4]) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) cacc = step(wv[i], xv[i >> 2][i & 3], cacc);
+    };
+    fetch(wa, xa, 0);
+#pragma unroll 1
+    for (int b = 0; b < RN_GRU / 16; b += 2) {  // (fenced: the scheduler otherwise sinks every fetch to its first use)
+      fetch(wb, xb, b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      run(wa, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b + 2 < RN_GRU / 16) fetch(wa, xa, b + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      run(wb, xb);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (chain_wave) {
+  auto chain_segment = [&](int seg) {
+    const float *x = L.cat + seg * RN_GRU;
+    if (vad_wave) chain_steps(O.vadw + seg * RN_GRU, 1, x, [](float w, float xv, float a) { return a + w * xv; });
+    else chain_steps(O.big + (seg & 1) * 12288 + ct, RN_NB_BANDS, x, [](float w, float xv, float a) { return fmaf(w, xv, a); });
+  };
+  if (chain_wave && !vad_wave) {
     fetch_segment(0);
     fetch_segment(1);
   }
   __syncthreads();
+  // what a GRU layer reads from global memory besides its weights -- old state, group bounds, epilogue vectors, diagonal --
+  // is requested one layer ahead (here for layer 0; inside layer k for k + 1): a dependent round trip costs 1.5-3.5 us
+  struct Smalls {
+    float h_old;
+    int g0[3], g1[3];
+    RowEpi e[3];
+    float dg[3];
+  };
+  auto smalls_fetch = [&](int k) {
+    Smalls q = {};
+    if (!chain_wave) {
+      const RowSrc wm = row_src_select(half, m.gru_in[k], m.gru_rec[k]);
+      q.h_old = g.gru_state[((size_t)k * g.n_stride + s) * RN_GRU + u];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int row = r * RN_GRU + u;
+        q.g0[r] = wm.grp4[row >> 3];
+        q.g1[r] = wm.grp4[(row >> 3) + 1];
+        q.e[r] = row_epi(wm, row);
+        if (half) q.dg[r] = wm.diag[row];
+      }
+    }
+    return q;
+  };
+  Smalls sm = smalls_fetch(0);
   // conv2: int8 dense 384 -> 384, tanh
-  if (!chain_wave) {
-    const RnLinearDev *const l1[1] = {&m.conv2};
-    const int r1[1] = {t};
-    const int *const x1[1] = {L.xq};
-    float o1[1];
-    int8_rows<1, 8>(l1, r1, x1, o1);
-    L.cat[t] = tanh_x86(o1[0], lut);
+  if (c2_thread) {
+    const int r1[1] = {u}, g0[1] = {c2g0}, g1[1] = {c2g1};
+    int a1[1];
+    int8_rows<1, 6>(c2, r1, g0, g1, L.xq, 0, 1, a1);
+    L.cat[u] = tanh_x86(int8_finish(c2e, a1[0]), lut);
   }
-  // three GRUs (src/nnet.c:65-94); thread = hidden unit
+  ONE_TAP();  // 2: conv2 (rows) / chain wave: segments 0 and 1 requested
+  // three GRUs (src/nnet.c:65-94): thread u of waves 0-5 the three input-matrix rows of hidden unit u and, after the exchange,
+  // its gates; thread u of waves 6-11 the three recurrent rows (+ diagonal), handed over through LDS
+  if (chain_wave) __builtin_amdgcn_s_setprio(3);  // (the chains are one long dependency: let their LDS reads and FMAs issue first)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    float h_old = 0;
+    const float h_old = sm.h_old;
     float *st = g.gru_state + ((size_t)k * g.n_stride + s) * RN_GRU;
-    if (!chain_wave) {
-      h_old = st[t];
-      L.cat[(k + 1) * RN_GRU + t] = h_old;
-    }
+    if (!chain_wave && !half) L.cat[(k + 1) * RN_GRU + u] = h_old;
     __syncthreads();  // segment k of cat is final (conv2 output / the previous layer's new state)
+    if (k == 0) ONE_TAP();  // 3: layer 0: barrier
     if (t < 96) L.xq[t] = pack4(L.cat + k * RN_GRU + 4 * t);
     else if (t >= 128 && t < 224) L.hq[t - 128] = pack4(L.cat + (k + 1) * RN_GRU + 4 * (t - 128));
     __syncthreads();
-    float h = 0;
+    if (k == 0) ONE_TAP();  // 4: layer 0: quantised inputs packed, barrier
+    Smalls nx = {};
+    int a3[3] = {0, 0, 0};
     if (chain_wave) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own DMA pieces: segment k's weights are in LDS
       chain_segment(k);
-      if (k + 2 <= 3) fetch_segment(k + 2);            // into the buffer the chain has just left
+      if (k + 2 <= 3 && !vad_wave) fetch_segment(k + 2);  // into the buffer the chain has just left
     } else {
-      const RnLinearDev &wi = m.gru_in[k], &wr = m.gru_rec[k];
-      const RnLinearDev *const l6[6] = {&wi, &wi, &wi, &wr, &wr, &wr};
-      const int r6[6] = {t, RN_GRU + t, 2 * RN_GRU + t, t, RN_GRU + t, 2 * RN_GRU + t};
-      const int *const x6[6] = {L.xq, L.xq, L.xq, L.hq, L.hq, L.hq};
-      float o6[6];
-      int8_rows<6, 4>(l6, r6, x6, o6);
-      const float zi = o6[0], ri = o6[1], hi = o6[2];
-      float zr = o6[3], rr = o6[4], hr = o6[5];
-      zr += wr.diag[t] * h_old;  // src/nnet_arch.h:153-161
-      rr += wr.diag[RN_GRU + t] * h_old;
-      hr += wr.diag[2 * RN_GRU + t] * h_old;
-      const float z = sigmoid_x86(zi + zr, lut);
-      const float r = sigmoid_x86(ri + rr, lut);
-      h = tanh_x86(hi + hr * r, lut);
+      if (k < 2) nx = smalls_fetch(k + 1);
+      const RowSrc wm = row_src_select(half, m.gru_in[k], m.gru_rec[k]);
+      const int r3[3] = {u, RN_GRU + u, 2 * RN_GRU + u};
+      int8_rows<3, 3>(wm, r3, sm.g0, sm.g1, half ? L.hq : L.xq, 0, 1, a3);
+      if (k == 0) ONE_TAP();  // 5: layer 0: row products
+      if (half) {  // recurrent sums + diagonal (src/nnet_arch.h:153-161) -> LDS
+#pragma unroll
+        for (int r = 0; r < 3; r++) O.ex[r][u] = int8_finish(sm.e[r], a3[r]) + sm.dg[r] * h_old;
+      }
+    }
+    __syncthreads();  // the recurrent sums are in LDS (and every reader of the old state image is long done)
+    if (k == 0) ONE_TAP();  // 6: layer 0: exchange barrier (waits for the slowest wave, the chains included)
+    if (!chain_wave && !half) {
+      const float zi = int8_finish(sm.e[0], a3[0]), ri = int8_finish(sm.e[1], a3[1]), hi = int8_finish(sm.e[2], a3[2]);
+      const float z = sigmoid_x86(zi + O.ex[0][u], lut);
+      const float r = sigmoid_x86(ri + O.ex[1][u], lut);
+      float h = tanh_x86(hi + O.ex[2][u] * r, lut);
       h = z * h_old + (1 - z) * h;
+      L.cat[(k + 1) * RN_GRU + u] = h;
+      st[u] = h;
     }
-    __syncthreads();  // every reader of the old state (hq) is done
-    if (!chain_wave) {
-      L.cat[(k + 1) * RN_GRU + t] = h;
-      st[t] = h;
-    }
+    if (k == 0) ONE_TAP();  // 7: layer 0: gates
+    sm = nx;
   }
   __syncthreads();
   if (chain_wave) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     chain_segment(3);
-    if (ct < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + ct] = sigmoid_x86(dacc + m.dense_out.bias[ct], lut);
-    else if (ct == RN_NB_BANDS) g.vad[s] = sigmoid_x86(vacc + m.vad_dense.bias[0], lut);
+    if (!vad_wave && lane < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + ct] = sigmoid_x86(cacc + m.dense_out.bias[ct], lut);
+    else if (vad_wave && lane == 0) g.vad[s] = sigmoid_x86(cacc + m.vad_dense.bias[0], lut);
   }
+  ONE_TAP();  // 6: last chain segment + outputs
+#undef ONE_TAP
 }
 
 extern "C" hipError_t rn_launch_nn_one(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e0,

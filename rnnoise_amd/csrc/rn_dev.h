@@ -62,7 +62,8 @@ struct RnLinearDev {
   const uint16_t *cols;   // [nblocks] first input column of each block
   // the same int8 weights once more, row-major for the vector path (shim.cpp: model_on_device): a row's bytes of FOUR
   // consecutive blocks of its group are one 16-byte chunk, a group's list padded with zero blocks to a multiple of four --
-  //   wrow [((grp4[g] * 8 + (row & 7) * nch + c) * 4 .. + 3]   chunk c of a row of group g (nch = grp4[g+1] - grp4[g] chunks)
+  //   wrow [(((grp4[g] + c) * 8 + (row & 7)) * 4 .. + 3]       chunk c of a row of group g (grp4[g+1] - grp4[g] chunks; the eight
+  //                                                            rows' chunks c are one 128-byte line)
   //   cq   [grp4[g] + c]                                       input dword (column / 4) of the chunk's four blocks, one byte each
   // so a lane fetches four blocks per load instruction instead of one (the texture addresser spends as long on a 4-byte
   // load as on a 16-byte one: it, not the cache, paced the row products)

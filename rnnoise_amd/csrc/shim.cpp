@@ -779,13 +779,13 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
       std::vector<int32_t> wrow((size_t)g4[ng] * 8 * 4, 0);
       std::vector<uint32_t> cq((size_t)g4[ng], 0);
       for (int g = 0; g < ng; g++) {
-        const int nch = g4[g + 1] - g4[g], len = grp[g + 1] - grp[g];
+        const int len = grp[g + 1] - grp[g];
         for (int k = 0; k < len; k++) {
           const int b = grp[g] + k;
           const uint32_t col4 = o.has_cols ? cols[b] >> 2 : (uint32_t)k;
           cq[g4[g] + k / 4] |= col4 << (8 * (k & 3));
           for (int sub = 0; sub < 8; sub++)
-            memcpy(&wrow[((size_t)(g4[g] * 8 + sub * nch + k / 4)) * 4 + (k & 3)], w + (size_t)b * 32 + sub * 4, 4);
+            memcpy(&wrow[((size_t)(g4[g] + k / 4) * 8 + sub) * 4 + (k & 3)], w + (size_t)b * 32 + sub * 4, 4);
         }
       }
       o_w[i] = rows.add(wrow.data(), 4 * wrow.size());
