@@ -1,11 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r3h; mkdir -p $O
 cd "$R"; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q > "$O/pytest_gpu.txt" 2>&1; echo "pytest rc=$?" >> "$O/pytest_gpu.txt"
-grep -v "^  \|^$" "$O/pytest_gpu.txt" | tail -5
-cd /tmp
-python "$R/tools/serial_times.py" 1 64 1024 4096 16384 65536 2>&1 | grep "N=" | tee $O/serial_times.txt
-python "$R/tools/serial_times.py" --vector 256 512 2>&1 | grep "N="
-python "$R/tools/configs0.py" 2>&1 | grep "configs" | tee $O/configs0.txt
+python -c "
+import lzma; open('/tmp/w.blob','wb').write(lzma.decompress(open('tests/golden/default.blob.xz','rb').read()))"
+gcc -O2 -Iinclude tools/configs0_mt.c -o /tmp/configs0_mt -Lrnnoise_amd -l:librnnoise_amd.so -Wl,-rpath,$R/rnnoise_amd -lpthread
+for t in 1 2 4 8 16; do /tmp/configs0_mt /tmp/w.blob $t 2000 2>&1 | grep configs; done
+GPU_MAX_HW_QUEUES=8 /tmp/configs0_mt /tmp/w.blob 8 2000 2>&1 | grep configs
 true
