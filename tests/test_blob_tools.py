@@ -55,9 +55,10 @@ def test_cli_info(tmp_path, capsys, blob_default):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("density,path", [(1.0, 1), (1.0, 0), (0.1, 1)])
+@pytest.mark.parametrize("density,path", [(1.0, 1), (1.0, 0), (0.1, 1), (0.1, 0)])
 def test_synthetic_models_on_gpu(density, path):
-    """dense (largest index lists, SURVEY config stress) and very sparse models, both network paths"""
+    """dense (largest index lists, SURVEY config stress) and very sparse models (short, ragged block lists: chunks of the
+    row-major copy padded with zero blocks), both network paths"""
     b = rb.synth_model(seed=11, density=density)
     m = capi.Model(b)
     pcm = synth.batch_pcm([0, 5, 9], 30, lead_silence=2)

@@ -489,7 +489,9 @@ def test_mfma_path_bit_exact(model, blob_default, n, path):
     pcm[20:26, 1::4] = 0      # others go silent mid-way (state must freeze, src/denoise.c:474)
     uniq = sorted({(i, s % 3 == 0, s % 4 == 1) for s, i in enumerate(ids)})
     b = capi.Batch(model, n)
-    assert b.set_nn_path(path) == (1 if n > 256 else 0)   # documented default: up to 256 streams the latency-oriented vector kernel
+    import os
+    one_max = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "256"))  # (test_throughput_kernels_at_small_sizes re-runs this with 0)
+    assert b.set_nn_path(path) == (1 if n > one_max and n >= 16 else 0)   # documented default: up to 256 streams the latency-oriented vector kernel
     out, vad, gains = b.process(pcm)
     cache = {}
     for s, i in enumerate(ids):
@@ -578,6 +580,25 @@ def test_other_stream_schedules_forced(mode):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
                         "test_pipeline_chunking or test_device_call_in_place or test_mfma_path_bit_exact"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_throughput_kernels_at_small_sizes():
+    """Small batches run the latency-oriented kernels by default (rn_hp_one_kernel up to 3072 streams, rn_nn_one_kernel up to
+    256 on the vector path); with both switched off ($RNNOISE_AMD_HP_ONE_MAX / $RNNOISE_AMD_NN_ONE_MAX = 0, read once per
+    process) the same cases go through rn_hp_kernel and rn_nn_vector_kernel -- the kernels of larger batches -- and must give
+    the same bits"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RNNOISE_AMD_NN_ONE_MAX"):
+        pytest.skip("already inside a forced run")
+    env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, os.path.join(root, "tests", "test_blob_tools.py"), "-k",
+                        "test_mfma_path_bit_exact or test_synthetic_models_on_gpu or test_s16_entry_points or test_drop_in_single_stream_api"],
+                       env=env, capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
