@@ -105,7 +105,10 @@ __device__ __forceinline__ RowSrc row_src_select(bool second, const RnLinearDev 
 // the CU's LDS pipe busy for ~10 k cycles per GRU layer, and the dense_out / vad chains on their own waves, which live on
 // LDS operands, crawled behind them: 32 k cycles per layer, THE critical path.)
 template <int J>
-__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, true); }  // (bound_ctrl: no old value to keep, no register zeroed per broadcast)
+// (tried: the broadcast as a DPP modifier of the dot product itself -- v_dot4c_i32_i8_dpp assembles for gfx950 and would make
+//  it one instruction per block instead of three -- from inline asm: the kernel then faults on the MI355X; hipcc's DPP combiner
+//  does not form it either.  Left as v_mov_b32_dpp + v_dot4c.)
 template <int NR, int U>
 __device__ __forceinline__ void int8_rows(const RowSrc &l, const int (&row)[NR], const int (&g0a)[NR], const int (&g1a)[NR], const int *xq,
                                           int part, int nparts, int (&acc)[NR]) {
@@ -315,7 +318,7 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   float *dbg = (g.debug && (t == 0 || t == ONE_ROW_THREADS)) ? g.debug + (size_t)s * RN_DBG_FLOATS + RN_DBG_CLK2 + (t ? 8 : 0) : nullptr;
   unsigned long long clk_prev = g.debug ? __builtin_amdgcn_s_memtime() : 0;
   int tap_i = 0;
-#define ONE_TAP() do { if (g.debug) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (dbg && tap_i < 8 - (t ? 2 : 0)) dbg[tap_i] = (float)(now_ - clk_prev); tap_i++; clk_prev = now_; } } while (0)
+#define ONE_TAP() do { if (g.debug) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (dbg && tap_i < 8) dbg[tap_i] = (float)(now_ - clk_prev); tap_i++; clk_prev = now_; } } while (0)
 #else
 #define ONE_TAP() do { } while (0)
 #endif
@@ -362,12 +365,15 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   ONE_TAP();  // 1: conv1
   if (t < 96) L.xq[t] = pack4(L.tmp2 + 4 * t);
   if (t >= 128 && t < RN_GRU) c2s[t - 128] = L.tmp2[t];  // conv2 history <- tmp2[128..383]
-  // dense_out weights of cat segment `seg` (384 x 32 floats, contiguous, 48 pieces) -> LDS buffer seg & 1, by the chain wave
-  auto fetch_segment = [&](int seg) {
-    const char *src = reinterpret_cast<const char *>(m.dense_out.fw) + (size_t)seg * 49152 + lane * 16;
+  // dense_out weights of cat segment `seg` (fw4 order, 48 KB contiguous = 48 pieces) -> LDS buffer seg & 1.  Segment 0 by the
+  // dense_out wave during conv2; segment k + 1 by the twelve row waves, four pieces each, at the start of GRU layer k (its
+  // buffer was last read by chain k - 1, one barrier ago).  (One wave issuing all 48 pieces after its chain spent 7 k cycles
+  // in the issue alone -- the memory pipeline takes a 1 KB piece every ~150 cycles from one wave -- and everybody waited for it
+  // at the layer's barrier.)
+  auto fetch_pieces = [&](int seg, int first, int count) {
+    const char *src = reinterpret_cast<const char *>(m.dense_out.fw4) + (size_t)seg * 49152 + lane * 16;
     const unsigned dst = one_lds_addr(O.big) + (seg & 1) * 49152;
-#pragma unroll
-    for (int i = 0; i < 48; i++) one_dma_1k(src + i * 1024, dst + i * 1024);
+    for (int i = first; i < first + count; i++) one_dma_1k(src + i * 1024, dst + i * 1024);
   };
   // The chains over one segment of cat, 384 steps each, wave-uniform code (wave 12: lanes = the 32 dense_out outputs, one
   // fmaf per step; wave 13: every lane the same vad chain, the scalar tail of sgemv, src/vec_avx.h:732-736: unfused mul + add).
@@ -377,18 +383,19 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   float cacc = 0;
   // (two copies of the loop behind a wave-uniform branch: with the mul + add / fmaf choice INSIDE the loop the compiler computed
   //  both and selected per step -- a v_cndmask on VCC in the dependency chain, 16-19 clocks each: 73 cycles per step)
-  auto chain_steps = [&](const float *w, int ws, const float *x, auto step) {
-    float wa[16], wb[16];
-    v4f_t xa[4], xb[4];
-    auto fetch = [&](float (&wv)[16], v4f_t (&xv)[4], int b) {
+  // w4: the chain's weights, four consecutive steps per 16 bytes (dense_out: rn_dev.h fw4 order, one 16-byte slot per output
+  // and group of four inputs; vad_dense: its 1536 weights as they are, the same slot for every lane)
+  auto chain_steps = [&](const v4f_t *w4, int ws4, const float *x, auto step) {
+    v4f_t wa[4], wb[4], xa[4], xb[4];
+    auto fetch = [&](v4f_t (&wv)[4], v4f_t (&xv)[4], int b) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) wv[i] = w[(16 * b + i) * ws];
+      for (int i = 0; i < 4; i++) wv[i] = w4[(4 * b + i) * ws4];
 #pragma unroll
       for (int i = 0; i < 4; i++) xv[i] = *reinterpret_cast<const v4f_t *>(x + 16 * b + 4 * i);
     };
-    auto run = [&](const float (&wv)[16], const v4f_t (&xv)[4]) {
+    auto run = [&](const v4f_t (&wv)[4], const v4f_t (&xv)[4]) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) cacc = step(wv[i], xv[i >> 2][i & 3], cacc);
+      for (int i = 0; i < 16; i++) cacc = step(wv[i >> 2][i & 3], xv[i >> 2][i & 3], cacc);
     };
     fetch(wa, xa, 0);
 #pragma unroll 1
@@ -405,13 +412,10 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   };
   auto chain_segment = [&](int seg) {
     const float *x = L.cat + seg * RN_GRU;
-    if (vad_wave) chain_steps(O.vadw + seg * RN_GRU, 1, x, [](float w, float xv, float a) { return a + w * xv; });
-    else chain_steps(O.big + (seg & 1) * 12288 + ct, RN_NB_BANDS, x, [](float w, float xv, float a) { return fmaf(w, xv, a); });
+    if (vad_wave) chain_steps(reinterpret_cast<const v4f_t *>(O.vadw + seg * RN_GRU), 1, x, [](float w, float xv, float a) { return a + w * xv; });
+    else chain_steps(reinterpret_cast<const v4f_t *>(O.big + (seg & 1) * 12288) + ct, RN_NB_BANDS, x, [](float w, float xv, float a) { return fmaf(w, xv, a); });
   };
-  if (chain_wave && !vad_wave) {
-    fetch_segment(0);
-    fetch_segment(1);
-  }
+  if (chain_wave && !vad_wave) fetch_pieces(0, 0, 48);
   __syncthreads();
   // what a GRU layer reads from global memory besides its weights -- old state, group bounds, epilogue vectors, diagonal --
   // is requested one layer ahead (here for layer 0; inside layer k for k + 1): a dependent round trip costs 1.5-3.5 us
@@ -460,13 +464,18 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     else if (t >= 128 && t < 224) L.hq[t - 128] = pack4(L.cat + (k + 1) * RN_GRU + 4 * (t - 128));
     __syncthreads();
     if (k == 0) ONE_TAP();  // 4: layer 0: quantised inputs packed, barrier
+#if RN_INSTRUMENT
+    const unsigned long long phase_clk = g.debug ? __builtin_amdgcn_s_memtime() : 0;
+#endif
     Smalls nx = {};
     int a3[3] = {0, 0, 0};
     if (chain_wave) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own DMA pieces: segment k's weights are in LDS
+      if (k == 0) ONE_TAP();  // chain wave 5: layer 0: waited for its DMA
       chain_segment(k);
-      if (k + 2 <= 3 && !vad_wave) fetch_segment(k + 2);  // into the buffer the chain has just left
+      if (k == 0) ONE_TAP();  // chain wave 6: layer 0: chain segment
     } else {
+      fetch_pieces(k + 1, 4 * wave, 4);  // (asm-issued: drained by the explicit wait below, before the layer's barrier)
       if (k < 2) nx = smalls_fetch(k + 1);
       const RowSrc wm = row_src_select(half, m.gru_in[k], m.gru_rec[k]);
       const int r3[3] = {u, RN_GRU + u, 2 * RN_GRU + u};
@@ -477,6 +486,11 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
         for (int r = 0; r < 3; r++) O.ex[r][u] = int8_finish(sm.e[r], a3[r]) + sm.dg[r] * h_old;
       }
     }
+    if (!chain_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next segment have landed
+#if RN_INSTRUMENT
+    if (k == 0 && g.debug && lane == 0)  // arrival of every wave at layer 0's exchange barrier, clocks since its pack barrier
+      g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_CLK2 + 16 + wave] = (float)(__builtin_amdgcn_s_memtime() - phase_clk);
+#endif
     __syncthreads();  // the recurrent sums are in LDS (and every reader of the old state image is long done)
     if (k == 0) ONE_TAP();  // 6: layer 0: exchange barrier (waits for the slowest wave, the chains included)
     if (!chain_wave && !half) {

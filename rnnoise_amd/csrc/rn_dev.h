@@ -70,6 +70,8 @@ struct RnLinearDev {
   const int *wrow;
   const uint32_t *cq;
   const int *grp4;        // [nout/8 + 1]
+  const float *fw4;       // dense_out only: the float weights as [input / 4][output][input % 4] -- a lane of the one-stream
+                          //   kernel's chain wave reads the weights of four consecutive steps of ITS output as one 16-byte LDS read
   int nin, nout;
 };
 

@@ -792,6 +792,15 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
       o_c[i] = rows.add(cq.data(), 4 * cq.size());
       o_g[i] = rows.add(g4.data(), 4 * g4.size());
     }
+    size_t o_fw4 = 0;
+    {  // dense_out (layer 8), float: [input / 4][output][input % 4]
+      const float *fw = reinterpret_cast<const float *>(sm.st.bytes.data() + sm.off[8].fw);
+      const int nin = sm.lin[8].nin, nout = sm.lin[8].nout;
+      std::vector<float> fw4((size_t)nin * nout);
+      for (int j = 0; j < nin; j++)
+        for (int i = 0; i < nout; i++) fw4[((size_t)(j / 4) * nout + i) * 4 + (j & 3)] = fw[(size_t)j * nout + i];
+      o_fw4 = rows.add(fw4.data(), 4 * fw4.size());
+    }
     HIP_OK(hipMalloc(&d.mem_rows, rows.bytes.size()));
     HIP_OK(hipMemcpy(d.mem_rows, rows.bytes.data(), rows.bytes.size(), hipMemcpyHostToDevice));
     const uint8_t *rb = static_cast<const uint8_t *>(d.mem_rows);
@@ -800,6 +809,7 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
       dst[i]->cq = reinterpret_cast<const uint32_t *>(rb + o_c[i]);
       dst[i]->grp4 = reinterpret_cast<const int *>(rb + o_g[i]);
     }
+    dst[8]->fw4 = reinterpret_cast<const float *>(rb + o_fw4);
   }
   m->dev.push_back(d);
   out = d.dev;

@@ -21,4 +21,6 @@ names = ["DMA conv1 + inputs", "conv1", "conv2", "L0 barrier", "L0 pack + barrie
 rows, chain = d[:, 1360:1368], d[:, 1368:1376]
 print(f"rn_nn_one_kernel, {n} stream(s), shader clocks (100 MHz s_memtime ticks x 24 = 2.4 GHz cycles?) -- thread 0 | chain wave")
 for k, nm in enumerate(names):
-    print(f"  {nm:<34}{rows[:, k].mean():>10.0f}{chain[:, k].mean() if k < 6 else 0:>10.0f}")
+    print(f"  {nm:<34}{rows[:, k].mean():>10.0f}{chain[:, k].mean():>10.0f}")
+print("  (chain wave, from slot 5 on: waited for its DMA | chain segment 0 | segment 2 requested + exchange barrier)")
+print("  arrival of waves 0..13 at layer 0's exchange barrier (clocks after its pack barrier):", " ".join(f"{v:.0f}" for v in d[:, 1376:1390].mean(0)))
