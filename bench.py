@@ -79,7 +79,7 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
     three of the five and the longest."""
     if kind == "network":
         if nn != "mfma":
-            return "rn_nn_one_kernel" if n_streams <= 256 else "rn_nn_vector_kernel"  # shim.cpp: nn_one_max_streams()
+            return "rn_nn_one_kernel" if n_streams <= 512 else "rn_nn_vector_kernel"  # shim.cpp: nn_one_max_streams()
         return "rn_nn_gru_kernel" if n_streams >= NN_LAYERS_MIN_STREAMS else "rn_nn_mfma_kernel"
     if kind == "analysis" and n_streams < 6144:
         return "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)

@@ -83,7 +83,7 @@ RNNOISE_EXPORT int rnnoise_batch_import_state(RNNoiseBatch *b, int stream, const
 /* Network implementation: 0 = vector path (v_dot4 / FMA chains), 1 = batched MFMA path -- one kernel per 16-stream tile
  * below 16,384 streams, layer by layer (64 streams per GRU workgroup, five launches) from there up --, 2 = the layer-wise
  * MFMA schedule whatever the batch size (tests, A/B runs).  All produce identical bits and share all state: the path may
- * be switched between calls.  Default: 0 up to 256 streams (there path 0 runs as a latency-oriented kernel, one workgroup per
+ * be switched between calls.  Default: 0 up to 512 streams (there path 0 runs as a latency-oriented kernel, one workgroup per
  * stream, which finishes before a 16-stream MFMA tile does), 1 beyond.
  * Returns the previous value, or -1 if unsupported. */
 RNNOISE_EXPORT int rnnoise_batch_set_nn_path(RNNoiseBatch *b, int path);

@@ -249,7 +249,7 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *g, const RnModelDev 
 
 // ---------------------------------------------------------------------------------------------
 // K2 for a handful of streams (the one-stream states behind rnnoise_process_frame, include/rnnoise.h:94, and batches of up to
-// 256 streams): the same network and the same bits as rn_nn_vector_kernel, arranged for LATENCY.  One workgroup of 14 waves
+// 512 streams): the same network and the same bits as rn_nn_vector_kernel, arranged for LATENCY.  One workgroup of 14 waves
 // per stream:
 //   * waves 0-5: thread u = the three input-matrix rows of hidden unit u (and conv2's row u, and the unit's gates); waves 6-11:
 //     thread u = the three recurrent rows (+ diagonal), handed to the gate thread through LDS.  Row products come from the

@@ -834,11 +834,11 @@ int nn_layers_min_streams() {
 }
 
 // Up to this many streams the vector-path network runs as the latency-oriented kernel (nn_kernels.hip: rn_nn_one_kernel, one
-// 7-wave workgroup with 114 KB of LDS per stream -- one per CU); $RNNOISE_AMD_NN_ONE_MAX overrides (A/B runs, 0 = never).
+// 14-wave workgroup with 125 KB of LDS per stream -- one per CU, two rounds at 512 streams); $RNNOISE_AMD_NN_ONE_MAX overrides (A/B runs, 0 = never).
 int nn_one_max_streams() {
   static const int v = [] {
     const char *e = getenv("RNNOISE_AMD_NN_ONE_MAX");
-    return e ? atoi(e) : 256;
+    return e ? atoi(e) : 512;
   }();
   return v;
 }
@@ -1004,9 +1004,9 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
   b->model = model;
   b->device = device;
   b->n = n_streams;
-  // same bits either way.  Up to 256 streams the latency-oriented vector kernel (one 7-wave workgroup per stream, each on a CU
-  // of its own) finishes first -- measured K2 at 16 / 64 / 256 streams: 58 / 58 / 78 us against 66 / 82 / 101 us for MFMA tiles
-  // of 16 streams; beyond that the MFMA paths do
+  // same bits either way.  Up to 512 streams the latency-oriented vector kernel (one 14-wave workgroup per stream, one per CU)
+  // finishes first -- measured K2 at 64 / 256 / 512 / 768 streams: 36 / 42 / 83 / 120 us against 82 / 101 / 105 / 105 us for MFMA
+  // tiles of 16 streams; beyond that the MFMA paths do
   b->nn_path = (n_streams > nn_one_max_streams() && n_streams >= 16 && rn_nn_mfma_available()) ? 1 : 0;
   if (model_on_device(model, device, b->m) || tables_for_device(device, b->tb)) {
     delete b;

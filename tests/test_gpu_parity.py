@@ -490,8 +490,8 @@ def test_mfma_path_bit_exact(model, blob_default, n, path):
     uniq = sorted({(i, s % 3 == 0, s % 4 == 1) for s, i in enumerate(ids)})
     b = capi.Batch(model, n)
     import os
-    one_max = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "256"))  # (test_throughput_kernels_at_small_sizes re-runs this with 0)
-    assert b.set_nn_path(path) == (1 if n > one_max and n >= 16 else 0)   # documented default: up to 256 streams the latency-oriented vector kernel
+    one_max = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))  # (test_throughput_kernels_at_small_sizes re-runs this with 0)
+    assert b.set_nn_path(path) == (1 if n > one_max and n >= 16 else 0)   # documented default: up to 512 streams the latency-oriented vector kernel
     out, vad, gains = b.process(pcm)
     cache = {}
     for s, i in enumerate(ids):
@@ -586,7 +586,7 @@ def test_other_stream_schedules_forced(mode):
 
 def test_throughput_kernels_at_small_sizes():
     """Small batches run the latency-oriented kernels by default (rn_hp_one_kernel up to 3072 streams, rn_nn_one_kernel up to
-    256 on the vector path); with both switched off ($RNNOISE_AMD_HP_ONE_MAX / $RNNOISE_AMD_NN_ONE_MAX = 0, read once per
+    512 on the vector path); with both switched off ($RNNOISE_AMD_HP_ONE_MAX / $RNNOISE_AMD_NN_ONE_MAX = 0, read once per
     process) the same cases go through rn_hp_kernel and rn_nn_vector_kernel -- the kernels of larger batches -- and must give
     the same bits"""
     import os
