@@ -576,7 +576,6 @@ struct RNNoiseBatch {
     // pinned callers: a ring of RING frame slots, filled and drained frame by frame beside the kernels
     static constexpr int RING = 6;
     char *ring_mem = nullptr;
-    size_t ring_frame_bytes = 0;   // PCM bytes of one slot (sized for float frames)
     hipEvent_t r_k3[RING] = {}, r_down[RING] = {}, r_up[RING] = {}, r_hp[RING] = {};
   } io;
   // timing
@@ -1325,7 +1324,6 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
                slot_g = (N * RN_NB_BANDS * 4 + 255) & ~size_t(255);
   if (!io.ring_mem) {
     HIP_OK(hipMalloc((void **)&io.ring_mem, RING * (2 * slot_pcm + slot_vad + slot_g)));
-    io.ring_frame_bytes = slot_pcm;
     for (int k = 0; k < RING; k++) {
       HIP_OK(hipEventCreateWithFlags(&io.r_k3[k], hipEventDisableTiming));  // (a copy engine follows a kernel: system scope)
       HIP_OK(hipEventCreateWithFlags(&io.r_down[k], hipEventDisableTiming));
@@ -1338,13 +1336,12 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   float *r_vad = reinterpret_cast<float *>(r_out + RING * slot_pcm), *r_g = reinterpret_cast<float *>(reinterpret_cast<char *>(r_vad) + RING * slot_vad);
   FrameIoHooks hk;
   hk.ring = RING;
-  // Uploads ride on the stream of their consumer, the high-pass (1.4 ms of DMA + 0.2 ms of kernel per 65,536-stream s16
-  // frame, in stream order: no events, and upload(f) follows high-pass(f - RING) by construction).  A stream of their own
-  // made five streams with the pipeline's three and the download's: the runtime multiplexes streams onto four hardware
-  // queues, and the two copy directions ended up serialised behind one another (measured: 21 M instead of 29 M frames/s).
-  // $RNNOISE_AMD_HOSTIO_COPY (A/B runs): "one" = uploads and downloads alternate on ONE copy stream, so that each finds the
-  // DMA engine free (two copies in flight make the runtime run one of them as a blit kernel); "hp" = uploads on the
-  // high-pass stream, downloads on the copy stream.
+  // Copies.  Uploads and downloads ALTERNATE ON ONE COPY STREAM (io.down), in the order the frame pipeline asks for them:
+  // each then finds the DMA engine free.  With two copies in flight the runtime executes one of them as a blit kernel (256
+  // workgroups x 512 lanes) whose PCIe-bound stores stall what runs beside it -- the analysis kernel took 2.3 ms instead of
+  // 1.1 (rocprofv3 kernel + memory-copy trace) -- and a copy stream per direction plus the pipeline's three streams is more
+  // than the four hardware queues the runtime multiplexes streams onto.  $RNNOISE_AMD_HOSTIO_COPY=hp (A/B runs): uploads on
+  // the high-pass stream instead, downloads alone on the copy stream.
   static const bool one_copy_stream = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY"); return !e || !strcmp(e, "one"); }();
   hk.before_hp = [&](int f, hipStream_t sc) -> int {
     if (!one_copy_stream) {
@@ -1365,10 +1362,9 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     if (f >= RING) HIP_OK(hipStreamWaitEvent(st, io.r_down[f % RING], 0));
     return 0;
   };
-  // Downloads: by default a small copy kernel writing the caller's pinned memory through its device address
-  // (state_kernels.hip: rn_copy_to_host_kernel -- the runtime's own D2H turns into a 256-workgroup blit kernel whenever the DMA
-  // engine is busy with an upload, and that kernel doubles the duration of whatever runs beside it); $RNNOISE_AMD_D2H = "dma"
-  // keeps hipMemcpyAsync, "kernel:<workgroups>" sizes the copy kernel (A/B runs).
+  // Downloads are hipMemcpyAsync (DMA).  $RNNOISE_AMD_D2H=kernel:<workgroups> (A/B runs) replaces them by a small copy kernel
+  // writing the caller's pinned memory through its device address (state_kernels.hip: rn_copy_to_host_kernel): measured
+  // slower than the serialised DMA copies (18 M against 23-28 M frames/s), kept for the record.
   static const int d2h_blocks = [] {
     const char *e = getenv("RNNOISE_AMD_D2H");
     if (e && !strncmp(e, "kernel:", 7)) return std::max(1, atoi(e + 7));
@@ -1403,10 +1399,10 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     return 0;
   };
   // Stream budget: the runtime multiplexes HIP streams onto four hardware queues, one of which belongs to the application's
-  // own stream.  The three-stream frame pipeline plus the download stream would be four more, and the high-pass and analysis
-  // streams then share a queue: uploads (on the high-pass stream) queue up behind analysis kernels and the whole step
+  // own stream.  The three-stream frame pipeline plus the copy stream would be four more, and the high-pass and analysis
+  // streams then share a queue: what the high-pass stream carries queues up behind analysis kernels and the whole step
   // serialises (rocprofv3 trace: 3.5 ms per 65,536-stream s16 step).  Analysis therefore stays on the main stream here
-  // (schedule 1: only uploads + high-pass run ahead on a side stream), which costs the 2-3 % the analysis overlap is worth.
+  // (schedule 1: only the high-pass runs ahead on a side stream), which costs the 2-3 % the analysis overlap is worth.
   static const int sched_env = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_SCHEDULE"); return e ? atoi(e) : 1; }();  // (A/B runs)
   const int keep = b->schedule;
   if (b->schedule == 0) b->schedule = sched_env;
