@@ -51,9 +51,10 @@ RNNOISE_EXPORT int rnnoise_batch_size(const RNNoiseBatch *b);
 RNNOISE_EXPORT int rnnoise_batch_reset(RNNoiseBatch *b);
 
 /* Host buffers; synchronous.  vad and gains may be NULL.  in may alias out. 0 / -1.
- * Internally a double-buffered pipeline: ~32 MB chunks, upload of chunk i+1 and download of chunk i-1 overlap the
- * kernels of chunk i.  Pinned host memory (hipHostMalloc / hipHostRegister) is used in place by DMA; pageable memory
- * goes through the library's pinned bounce buffers. */
+ * Pinned host memory (hipHostMalloc / hipHostRegister) is read and written by DMA in place, frame by frame, through a
+ * six-slot ring in HBM beside ONE pipelined multi-frame device call: a call pays one frame's upload before and one frame's
+ * download after its kernels whatever its length (use 16 frames or more per call when throughput matters).  Pageable
+ * memory goes through the library's pinned bounce buffers in ~32 MB chunks, two in flight. */
 RNNOISE_EXPORT int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
                                          int n_frames);
 

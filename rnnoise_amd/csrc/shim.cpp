@@ -1308,8 +1308,8 @@ static int host_io_prepare(RNNoiseBatch *b, int frames, size_t esz, bool bounce)
 }
 
 // Host-fed path for pinned caller memory (hipHostMalloc / hipHostRegister): the DMA engines read and write it in place, one
-// frame per copy, while ONE multi-frame device call runs the kernels as the three-stream frame pipeline over a ring of
-// RING frame slots in HBM.  Per frame f: upload(f) [after high-pass(f - RING) has read the slot] -> high-pass(f) -> ... ->
+// frame per copy, while ONE multi-frame device call runs the kernels as a frame pipeline (the high-pass up to three frames
+// ahead on a side stream) over a ring of RING frame slots in HBM.  Per frame f: upload(f) [after high-pass(f - RING) has read the slot] -> high-pass(f) -> ... ->
 // network(f), synthesis(f) [after download(f - RING) has drained the slot] -> download(f).  A call pays one frame's upload
 // before and one frame's download after its kernels, whatever its length.
 static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, float *vad, float *gains, int n_frames, bool s16) {
