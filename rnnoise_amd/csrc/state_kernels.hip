@@ -1,13 +1,14 @@
 // state_kernels.hip -- portable per-stream state (include/rn_layout.h: the 25,128 live bytes of the reference's
 // DenoiseState, src/denoise.c:68-88) <-> the batch's structure-of-arrays layout (rn_dev.h), on the device.
-// One launch moves `g.n_streams` states; the host side needs one memcpy per direction instead of one per field.
+// One launch moves `g.n_streams` states (a 1024-thread workgroup each: the per-word field dispatch is latency, 17 us with 256
+// threads); the host side needs one memcpy per direction instead of one per field.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rn_dev.h"
 
 // flat[s][RN_STATE_FLOATS] <- stream s of the view.  newest_slot = pitch-ring slot of the latest frame,
 // last = spectra slot of the latest frame (the reference's delayed_*).
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 rn_state_gather_kernel(RnGroupDev g, float *__restrict__ flat, int newest_slot, int last) {
   const size_t s = blockIdx.x, N = g.n_stride;
   float *f = flat + s * RN_STATE_FLOATS;
@@ -35,7 +36,7 @@ rn_state_gather_kernel(RnGroupDev g, float *__restrict__ flat, int newest_slot, 
 }
 
 // stream s of the view <- flat[s][RN_STATE_FLOATS] (analysis_mem is implied by pitch_buf and not stored)
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 rn_state_scatter_kernel(RnGroupDev g, const float *__restrict__ flat, int newest_slot, int last) {
   const size_t s = blockIdx.x, N = g.n_stride;
   const float *f = flat + s * RN_STATE_FLOATS;
@@ -65,11 +66,11 @@ rn_state_scatter_kernel(RnGroupDev g, const float *__restrict__ flat, int newest
 }
 
 extern "C" hipError_t rn_launch_state_gather(const RnGroupDev *g, float *flat, int newest_slot, int last, hipStream_t st) {
-  hipLaunchKernelGGL(rn_state_gather_kernel, dim3(g->n_streams), dim3(256), 0, st, *g, flat, newest_slot, last);
+  hipLaunchKernelGGL(rn_state_gather_kernel, dim3(g->n_streams), dim3(1024), 0, st, *g, flat, newest_slot, last);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *g, const float *flat, int newest_slot, int last, hipStream_t st) {
-  hipLaunchKernelGGL(rn_state_scatter_kernel, dim3(g->n_streams), dim3(256), 0, st, *g, flat, newest_slot, last);
+  hipLaunchKernelGGL(rn_state_scatter_kernel, dim3(g->n_streams), dim3(1024), 0, st, *g, flat, newest_slot, last);
   return hipGetLastError();
 }
 
