@@ -101,3 +101,36 @@ def test_rocprof_summary_lists_the_kernels_of_the_step():
         nn = ("rn_nn_mfma_kernel",) if f.startswith("r1_") else ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
         for k in ("rn_hp_kernel", "rn_analysis", "rn_synthesis_kernel") + nn:
             assert k in txt, (f, k)
+
+
+def test_new_bench_flags_and_valu_mix_table():
+    """round 3: --s16 / --frames-per-call / --no-parity parse; the per-kernel VALU price table (tools/valu_mix.py ->
+    profiles/valu_mix.json) covers every kernel of the step and stays between the measured class costs"""
+    a = bench.parse_args(["--s16", "--frames-per-call", "1", "--host-io", "--no-parity"])
+    assert a.s16 and a.frames_per_call == 1 and a.host_io and a.no_parity
+    assert "int16" in bench.workload_name(a, a.streams) and "1 frame(s) per call" in bench.workload_name(a, a.streams)
+    mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+    lo, hi = mix["cost"]["fast"], mix["cost"]["trans"]
+    for k in ("rn_hp_kernel", "rn_hp_one_kernel", "rn_analysis_kernel", "rn_analysis_single_kernel", "rn_nn_front_kernel",
+              "rn_nn_gru_kernel", "rn_nn_dense_kernel", "rn_nn_mfma_kernel", "rn_nn_one_kernel", "rn_nn_vector_kernel",
+              "rn_synthesis_kernel"):
+        r = mix["kernels"][k]
+        assert lo <= r["mean_cycles"] <= hi and r["fast"] + r["std"] + r["trans"] == r["valu_static"], k
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_mix
+    assert valu_mix.classify("v_fma_f32", "v1, v2, v3, v4") == "fast"
+    assert valu_mix.classify("v_add_f32_dpp", "v1, v2, v3 row_shr:1") == "std"
+    assert valu_mix.classify("v_add_f32_e32", "v1, s4, v3") == "std"       # an SGPR source costs the slow rate
+    assert valu_mix.classify("v_rcp_f32_e32", "v1, v2") == "trans" and valu_mix.classify("v_permlane32_swap_b32_e32", "v1, v2") == "trans"
+    assert valu_mix.classify("v_cndmask_b32_e32", "v1, v2, v3, vcc") == "std"
+
+
+def test_round3_bench_lines_carry_parity_and_the_new_rooflines():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_bench_*.json")))
+    assert len(files) >= 8
+    for f in files:
+        d = json.loads(open(f).read())
+        _check_line(d, f)
+        assert d["parity"]["bit_identical"] is True and d["parity"]["streams"] == 32, f
+        if "roofline_lds" in d:
+            assert 0 < d["roofline_lds"]["frac"] < 1 and 0 < d["roofline_valu"]["frac_f32_peak"] <= d["roofline_valu"]["frac"] < 1, f
