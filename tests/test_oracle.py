@@ -270,3 +270,34 @@ def test_live_reference_teacher_forced_state_import(blob_default):
     a, b = o.run(pcm[40:]), r.run(pcm[40:])
     for k in a:
         assert_bits_equal(a[k], b[k], k)
+
+
+def test_x86_float_to_short_model_matches_the_compiler(tmp_path):
+    """The int16 entry points (include/rnnoise_amd.h: rnnoise_batch_process_s16) convert on the device "as the reference's only
+    caller does" (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short).  Out of range that cast is undefined in C; what
+    the demo's binary DOES on x86-64 is cvttss2si / cvttps2dq to 32 bits ("integer indefinite" 0x80000000 when out of range or
+    NaN) and the low 16 bits of that.  This pins the model the GPU tests compare with (tests/test_gpu_parity.py:
+    x86_float_to_short) to what gcc emits on this host, scalar and vectorised."""
+    import ctypes as C
+    import subprocess
+    if os.uname().machine != "x86_64":
+        pytest.skip("x86 cast semantics")
+    src = tmp_path / "cast.c"
+    src.write_text("void cast_loop(const float *x, short *y, int n) { for (int i = 0; i < n; i++) y[i] = x[i]; }\n"
+                   "short cast_one(float x) { return x; }\n")
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-40000, 40000, 4096), rng.uniform(-3e9, 3e9, 4096), rng.uniform(-1e6, 1e6, 4096),
+                        [0.0, -0.0, 0.999, -0.999, 32767.5, -32768.5, 65535.9, 2147483520.0, 2147483648.0, -2147483648.0,
+                         -2147483904.0, 1e20, -1e20, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    ok = (x >= np.float32(-2147483648.0)) & (x < np.float32(2147483648.0))
+    model = (np.where(ok, np.trunc(np.where(ok, x, 0)), -2147483648.0).astype(np.int64) & 0xFFFF).astype(np.uint16).view(np.int16)
+    for opt in ("-O0", "-O2", "-O3 -mavx2"):
+        so = tmp_path / f"cast{opt.replace(' ', '')}.so"
+        subprocess.check_call(["gcc", *opt.split(), "-shared", "-fPIC", str(src), "-o", str(so)])
+        L = C.CDLL(str(so))
+        y = np.empty(x.size, np.int16)
+        L.cast_loop(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_short)), x.size)
+        assert np.array_equal(y, model), (opt, np.argwhere(y != model)[:5].tolist())
+        L.cast_one.restype = C.c_short
+        L.cast_one.argtypes = [C.c_float]
+        assert all(L.cast_one(float(v)) == int(m) for v, m in zip(x[-16:-1], model[-16:-1])), opt
