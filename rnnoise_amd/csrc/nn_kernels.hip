@@ -104,11 +104,6 @@ __device__ __forceinline__ RowSrc row_src_select(bool second, const RnLinearDev 
 // the quad shares them by DPP broadcast -- a quarter of the LDS instructions.  (With one read per block the row waves kept
 // the CU's LDS pipe busy for ~10 k cycles per GRU layer, and the dense_out / vad chains on their own waves, which live on
 // LDS operands, crawled behind them: 32 k cycles per layer, THE critical path.)
-template <int J>
-__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, true); }  // (bound_ctrl: no old value to keep, no register zeroed per broadcast)
-// (tried: the broadcast as a DPP modifier of the dot product itself -- v_dot4c_i32_i8_dpp assembles for gfx950 and would make
-//  it one instruction per block instead of three -- from inline asm: the kernel then faults on the MI355X; hipcc's DPP combiner
-//  does not form it either.  Left as v_mov_b32_dpp + v_dot4c.)
 template <int NR, int U>
 __device__ __forceinline__ void int8_rows(const RowSrc &l, const int (&row)[NR], const int (&g0a)[NR], const int (&g1a)[NR], const int *xq,
                                           int part, int nparts, int (&acc)[NR]) {
@@ -146,10 +141,21 @@ __device__ __forceinline__ void int8_rows(const RowSrc &l, const int (&row)[NR],
     for (int r = 0; r < NR; r++)
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        int t4 = __builtin_amdgcn_sdot4(w[r][u][0], quad_bcast<0>(x[r][u]), 0, false);
-        t4 = __builtin_amdgcn_sdot4(w[r][u][1], quad_bcast<1>(x[r][u]), t4, false);
-        t4 = __builtin_amdgcn_sdot4(w[r][u][2], quad_bcast<2>(x[r][u]), t4, false);
-        t4 = __builtin_amdgcn_sdot4(w[r][u][3], quad_bcast<3>(x[r][u]), t4, false);
+        int t4 = 0;
+        {
+          const int xv = x[r][u];
+          const v4i_t wv = w[r][u];
+          // v_dot4c_i32_i8 is a VOP2: the quad broadcast rides on its first operand as a DPP modifier, one instruction per block
+          // instead of three (zeroed register, v_mov_b32_dpp, v_dot4c; hipcc's DPP combiner does not form it).  From inline asm the
+          // hazard recogniser does not see a DPP instruction, so the five wait states a DPP operand may need after a VALU or
+          // EXEC write are spelled out (without them the kernel faulted).
+          asm volatile("s_nop 4\n\tv_dot4c_i32_i8_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                       "v_dot4c_i32_i8_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                       "v_dot4c_i32_i8_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                       "v_dot4c_i32_i8_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1"
+                       : "+v"(t4)
+                       : "v"(xv), "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]));
+        }
         acc[r] += (i + u < n[r]) ? t4 : 0;
       }
   }
