@@ -167,3 +167,14 @@ def test_rcp_profile_selection_is_host_side_and_named():
     with pytest.raises(ValueError):
         capi.set_rcp_profile("m68k")
     assert capi.rcp_profile() == name  # a rejected name changes nothing
+
+
+def test_c_thread_harness_compiles_against_the_drop_in_header(tmp_path):
+    """tools/configs0_mt.c (the pthread program behind profiles/r3_configs0_cthreads.txt) uses nothing but include/rnnoise.h"""
+    import subprocess
+    obj = tmp_path / "configs0_mt.o"
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c",
+                           os.path.join(ROOT, "tools", "configs0_mt.c"), "-o", str(obj)])
+    syms = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True, check=True).stdout
+    used = sorted(l.split()[-1] for l in syms.splitlines() if " rnnoise_" in l)
+    assert used == ["rnnoise_create", "rnnoise_destroy", "rnnoise_model_free", "rnnoise_model_from_filename", "rnnoise_process_frame"]
