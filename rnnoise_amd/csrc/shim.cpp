@@ -1264,10 +1264,12 @@ static void host_io_release(RNNoiseBatch *b) {
     if (io.up_done[k]) { hipEventDestroy(io.up_done[k]); hipEventDestroy(io.run_done[k]); hipEventDestroy(io.down_done[k]); }
   }
   if (io.up) hipStreamDestroy(io.up);
-  if (io.run) { hipStreamDestroy(io.run); hipStreamDestroy(io.down); }
+  if (io.run) hipStreamDestroy(io.run);
+  if (io.down) hipStreamDestroy(io.down);
   if (io.ring_mem) hipFree(io.ring_mem);
   for (int k = 0; k < RNNoiseBatch::HostIo::RING; k++)
-    if (io.r_k3[k]) { hipEventDestroy(io.r_k3[k]); hipEventDestroy(io.r_down[k]); hipEventDestroy(io.r_up[k]); hipEventDestroy(io.r_hp[k]); }
+    for (hipEvent_t e : {io.r_k3[k], io.r_down[k], io.r_up[k], io.r_hp[k]})
+      if (e) hipEventDestroy(e);
   io = RNNoiseBatch::HostIo();
 }
 
@@ -1316,19 +1318,26 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   RNNoiseBatch::HostIo &io = b->io;
   constexpr int RING = RNNoiseBatch::HostIo::RING;
   const size_t N = b->n, esz = s16 ? sizeof(short) : sizeof(float), fsz = N * RN_FRAME_SIZE * esz;
-  if (!io.run) {
-    HIP_OK(hipStreamCreateWithFlags(&io.run, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&io.down, hipStreamNonBlocking));
-  }
   const size_t slot_pcm = (N * RN_FRAME_SIZE * sizeof(float) + 255) & ~size_t(255), slot_vad = (N * 4 + 255) & ~size_t(255),
                slot_g = (N * RN_NB_BANDS * 4 + 255) & ~size_t(255);
-  if (!io.ring_mem) {
-    HIP_OK(hipMalloc((void **)&io.ring_mem, RING * (2 * slot_pcm + slot_vad + slot_g)));
-    for (int k = 0; k < RING; k++) {
-      HIP_OK(hipEventCreateWithFlags(&io.r_k3[k], hipEventDisableTiming));  // (a copy engine follows a kernel: system scope)
-      HIP_OK(hipEventCreateWithFlags(&io.r_down[k], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&io.r_up[k], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&io.r_hp[k], hipEventDisableTiming | hipEventDisableSystemFence));  // (read-after-read ordering only)
+  if (!io.ring_mem || !io.run) {  // streams, ring and events together or not at all: a half-built set is torn down and retried
+    auto build = [&]() -> int {
+      if (!io.run) {
+        HIP_OK(hipStreamCreateWithFlags(&io.run, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&io.down, hipStreamNonBlocking));
+      }
+      HIP_OK(hipMalloc((void **)&io.ring_mem, RING * (2 * slot_pcm + slot_vad + slot_g)));
+      for (int k = 0; k < RING; k++) {
+        HIP_OK(hipEventCreateWithFlags(&io.r_k3[k], hipEventDisableTiming));  // (a copy engine follows a kernel: system scope)
+        HIP_OK(hipEventCreateWithFlags(&io.r_down[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&io.r_up[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&io.r_hp[k], hipEventDisableTiming | hipEventDisableSystemFence));  // (read-after-read ordering only)
+      }
+      return 0;
+    };
+    if (build()) {
+      host_io_release(b);
+      return -1;
     }
   }
   // the slots are addressed with the stride of the CALL's frame size (s16 frames use the first half of a slot's room)
