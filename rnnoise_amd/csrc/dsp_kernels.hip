@@ -34,6 +34,22 @@ __device__ __constant__ int c_eband[RN_NB_BANDS + 2] = {
 
 __device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};  // src/pitch.c:422
 
+// ---- LDS pointers with their address space spelled out.  The chains below take their operands through pointers picked per
+// lane (this stream's arena or another's, the signal or its shifted copy); when such a pointer reaches a load as a generic
+// one the compiler emits flat_load, which the LDS serves at a fraction of a ds_read's rate (round 2's doubling dots and
+// fine-search chains ran on flat loads: 9-12 LDS cycles per instruction, profiles/r3_k1_sections_before.txt).
+#define LDS_AS __attribute__((address_space(3)))
+typedef const LDS_AS float *ldsf;
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define OPAQUE(v) asm("" : "+v"(v))
+__device__ __forceinline__ ldsf to_lds(const float *p) { return (ldsf)p; }
+__device__ __forceinline__ v4f_ lds_read16(ldsf p) { return *(const LDS_AS v4f_ *)p; }
+// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave, 256 B/clk): left alone, the load-store optimiser
+// fuses neighbouring ones into ds_read2_b64, which the LDS serves at half that rate (8 cycles per instruction,
+// MI355X_MICROARCH.md section LDS) -- in the chains below that doubled the cycles of the operand stream.
+__device__ __forceinline__ v2f lds_read8(ldsf p) { return *(const volatile LDS_AS v2f *)p; }
+
 // Band energy / correlation (src/denoise.c:90-138).  The reference's interleaved loop adds, for
 // every bin of band b, (1-frac)*tmp to sum[b] and frac*tmp to sum[b+1]; so accumulator k receives
 // band k-1's `frac` parts in bin order, then band k's `1-frac` parts.  Here all 64 lanes first form
@@ -44,50 +60,90 @@ __device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 
 // 64*j + fft_pos(l)).  Same arithmetic and per-accumulator order as band_accumulate above; the products go to LDS in the
 // layout of RnTablesDev::band_q -- accumulator k's terms contiguous from a 16-byte aligned slot -- so that the serial sums
 // read four terms per LDS instruction.  NX / NY: array lengths (only bins < 400, j = 0..6, are used).
-template <int NX, int NY>
+// NARR: number of product arrays formed side by side (1: <x, y>;  2: <y, y> into the first and <x, y> into the second, the Ep /
+// Exp pair of src/denoise.c:373-375, which share every table load and the y operand).
+template <int NARR, int NX, int NY>
 __device__ __forceinline__ void band_products(float *Q, const float (&xr)[NX], const float (&xi)[NX], const float (&yr)[NY],
-                                              const float (&yi)[NY], const RnTablesDev &tb, int pos) {
+                                              const float (&yi)[NY], const RnTablesDev &tb, int pos, int lane) {
   const uint32_t *band_q = tb.band_q;  // opaque copies: re-read from L1 at every call rather than kept across the pitch stage
   const float *band_frac = tb.band_frac;
-  asm volatile("" : "+s"(band_q), "+s"(band_frac));
+  const uint16_t *band_pad = tb.band_pad;
+  asm volatile("" : "+s"(band_q), "+s"(band_frac), "+s"(band_pad));
+  {  // the pad floats of every accumulator (RnTablesDev::band_pad): +0.0f
+    const int ps = band_pad[lane];
+    Q[ps] = 0.f;
+    if (NARR == 2) Q[RN_BAND_QSTRIDE + ps] = 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < 7; j++) {
     const int bin = WAVE * j + pos, bc = bin < 400 ? bin : 399;
     const uint32_t q = band_q[bc];
     const float frac = band_frac[bc];
-    float tmp = xr[j] * yr[j];
-    tmp += xi[j] * yi[j];
+    const float omf = 1 - frac;
+    float tmp = (NARR == 2 ? yr[j] : xr[j]) * yr[j];
+    tmp += (NARR == 2 ? yi[j] : xi[j]) * yi[j];
+    float tmp2 = 0;
+    if (NARR == 2) {
+      tmp2 = xr[j] * yr[j];
+      tmp2 += xi[j] * yi[j];
+    }
     if (bin < 400) {
       Q[(q >> 11) & 0x7ff] = frac * tmp;
-      Q[q & 0x7ff] = (1 - frac) * tmp;
+      Q[q & 0x7ff] = omf * tmp;
+      if (NARR == 2) {
+        Q[RN_BAND_QSTRIDE + ((q >> 11) & 0x7ff)] = frac * tmp2;
+        Q[RN_BAND_QSTRIDE + (q & 0x7ff)] = omf * tmp2;
+      }
     }
   }
 }
-// the 34 serial sums and the band vector (src/denoise.c:104-112); Q as written by band_products
+// The 34 serial sums (src/denoise.c:104-112) of NARR product arrays as written by band_products, in ONE pass: lane k < 34 adds
+// accumulator k of the first array; with two arrays, lane k + 30 (k = 4..33) adds accumulator k of the second at the same
+// time and lanes 0..3, whose own chains are one slot long, take its first four accumulators afterwards.  A lane reads its
+// chain 16 bytes at a time and leaves the loop when the chain ends (its length is rounded up to whole slots, the pad floats
+// are +0.0f), so a term costs one add -- the chain of the widest accumulator (83 terms) sets the pass's length, the 33 shorter
+// ones ride along.  sums: [40] per array.
+template <int NARR>
+__device__ __forceinline__ void band_sums(float *sums, const float *Q, const RnTablesDev &tb, int lane) {
+  const bool second = NARR == 2 && lane >= RN_NB_BANDS + 2;
+  const int k = second ? lane - 30 : (lane < RN_NB_BANDS + 2 ? lane : 0);
+  const uint32_t ch = tb.band_chain[k];
+  const int nt = (NARR == 1 && lane >= RN_NB_BANDS + 2) ? 0 : (int)(((ch >> 16) + 3) >> 2);
+  ldsf q = to_lds(Q) + (ch & 0xffff) + (second ? RN_BAND_QSTRIDE : 0);
+  RN_WSYNC();
+  float s = 0;
+#pragma unroll
+  for (int t = 0; t < 21; t++) {  // longest accumulator: 39 + 44 = 83 terms = 21 slots
+    if (t >= nt) break;
+    const v4f_ v = lds_read16(q + 4 * t);
+    s += v.x;
+    s += v.y;
+    s += v.z;
+    s += v.w;
+  }
+  if (nt) sums[second ? 40 + k : k] = s;
+  if (NARR == 2 && lane < 4) {  // accumulators 0..3 of the second array: 2, 4, 4, 4 terms (one slot each)
+    const v4f_ v = lds_read16(q + RN_BAND_QSTRIDE);
+    float s2 = 0;
+    s2 += v.x;
+    s2 += v.y;
+    s2 += v.z;
+    s2 += v.w;
+    sums[40 + lane] = s2;
+  }
+  RN_WSYNC();
+}
+// band vector from the 34 sums (the first and the last band take two accumulators each, src/denoise.c:109-112)
+__device__ __forceinline__ float band_of_sums(const float *sums, int lane) {
+  float v = sums[lane + 1];
+  if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
+  if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
+  return v;
+}
+// one band vector: sums + band_of_sums (Q as written by band_products<1>)
 __device__ __forceinline__ void band_chain(float *bandE, const float *Q, float *sums, const RnTablesDev &tb, int lane) {
-  RN_WSYNC();
-  {
-    const uint32_t ch = tb.band_chain[lane < RN_NB_BANDS + 2 ? lane : 0];
-    const int len = lane < RN_NB_BANDS + 2 ? (int)(ch >> 16) : 0;
-    const float4 *q = reinterpret_cast<const float4 *>(Q + (ch & 0xffff));
-    float s = 0;
-#pragma unroll 3
-    for (int t = 0; t < 21; t++) {  // longest accumulator: 39 + 44 = 83 terms; slots past `len` are not summed
-      const float4 v = q[t];
-      s += (4 * t + 0 < len) ? v.x : 0.f;
-      s += (4 * t + 1 < len) ? v.y : 0.f;
-      s += (4 * t + 2 < len) ? v.z : 0.f;
-      s += (4 * t + 3 < len) ? v.w : 0.f;
-    }
-    if (lane < RN_NB_BANDS + 2) sums[lane] = s;
-  }
-  RN_WSYNC();
-  if (lane < RN_NB_BANDS) {
-    float v = sums[lane + 1];
-    if (lane == 0) v = (sums[0] + sums[1]) * 2 / 3;
-    if (lane == RN_NB_BANDS - 1) v = (sums[RN_NB_BANDS] + sums[RN_NB_BANDS + 1]) * 2 / 3;
-    bandE[lane] = v;
-  }
+  band_sums<1>(sums, Q, tb, lane);
+  if (lane < RN_NB_BANDS) bandE[lane] = band_of_sums(sums, lane);
   RN_WSYNC();
 }
 
@@ -225,6 +281,44 @@ __device__ __forceinline__ void energy_sweeps_run(float *rsq, float *D, const fl
     b = bn;
   }
 }
+// The same two recurrences as functions of their own, one lane per stream each, for workgroups whose narrow phases are spread
+// over the waves (analysis_body): the fine Syy sweep and yy_lookup then advance at the same time on two SIMDs, and each
+// sheds the operation the shared form carried for the other's sake -- (s + a) - 0 == s + a and max(-inf, x) == x, so the
+// stored bits are those of energy_sweeps_run for every non-NaN operand.
+__device__ __forceinline__ void sweep_syy_fine(float *D, float syy0) {
+  D[-1] = syy0;
+  float s = syy0;
+  float4 a = *reinterpret_cast<const float4 *>(D);
+  for (int j = 0; j < 296; j += 4) {
+    const float4 an = *reinterpret_cast<const float4 *>(D + (j + 4 < 296 ? j + 4 : j));
+    float4 o;
+    s = fmaxf(1.f, s + a.x); o.x = s;
+    s = fmaxf(1.f, s + a.y); o.y = s;
+    s = fmaxf(1.f, s + a.z); o.z = s;
+    s = fmaxf(1.f, s + a.w); o.w = s;
+    *reinterpret_cast<float4 *>(D + j) = o;
+    a = an;
+  }
+}
+__device__ __forceinline__ void sweep_yy_lookup(float *rsq, float xx) {
+  rsq[479] = xx;
+  float s = xx;
+  float *pa = rsq + 480;
+  const float *pb = rsq;
+  float4 a = *reinterpret_cast<const float4 *>(pa), b = *reinterpret_cast<const float4 *>(pb);
+  for (int j = 0; j < 384; j += 4) {
+    const float4 an = *reinterpret_cast<const float4 *>(pa + j + 4);  // last one reads past the operands (inside the arena); unused
+    const float4 bn = *reinterpret_cast<const float4 *>(pb + j + 4);
+    float4 o;
+    s = (s + a.x) - b.x; o.x = s;
+    s = (s + a.y) - b.y; o.y = s;
+    s = (s + a.z) - b.z; o.z = s;
+    s = (s + a.w) - b.w; o.w = s;
+    *reinterpret_cast<float4 *>(pa + j) = o;
+    a = an;
+    b = bn;
+  }
+}
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
   return (float)(xy / sqrt((double)(1 + xx * yy)));
 }
@@ -238,22 +332,6 @@ __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // 
       clk_prev = now_;                                                       \
     }                                                                        \
   } while (0)
-
-// ---- LDS pointers with their address space spelled out.  The chains below take their operands through pointers picked per
-// lane (this stream's arena or another's, the signal or its shifted copy); when such a pointer reaches a load as a generic
-// one the compiler emits flat_load, which the LDS serves at a fraction of a ds_read's rate (round 2's doubling dots and
-// fine-search chains ran on flat loads: 9-12 LDS cycles per instruction, profiles/r3_k1_sections_before.txt).
-#define LDS_AS __attribute__((address_space(3)))
-typedef const LDS_AS float *ldsf;
-typedef float v4f_ __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-#define OPAQUE(v) asm("" : "+v"(v))
-__device__ __forceinline__ ldsf to_lds(const float *p) { return (ldsf)p; }
-__device__ __forceinline__ v4f_ lds_read16(ldsf p) { return *(const LDS_AS v4f_ *)p; }
-// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave, 256 B/clk): left alone, the load-store optimiser
-// fuses neighbouring ones into ds_read2_b64, which the LDS serves at half that rate (8 cycles per instruction,
-// MI355X_MICROARCH.md section LDS) -- in the chains below that doubled the cycles of the operand stream.
-__device__ __forceinline__ v2f lds_read8(ldsf p) { return *(const volatile LDS_AS v2f *)p; }
 
 // dot-product chain (src/pitch.h:51-142: one serial `sum = sum + x*y` per lag), n a multiple of 8,
 // x 16-byte aligned, y arbitrary; both may differ per lane.  The next 8 operand pairs are fetched
@@ -410,9 +488,10 @@ struct AnalysisLds {
 #define SCR_DOTS 2120 // [64]  doubling dots (behind yy_lookup, over the dead fine xcorr)
 #define SCR_YYL 1732  // [385] yy_lookup after the fine search (over the dead Syy / fine xcorr areas)
 #define SCR_XS 864    // [864] x_lp shifted by one sample, for the 8-byte reads of the doubling dots (over the dead squares)
-#define SCR_Q 960     // [1052] band products in the layout of RnTablesDev::band_q (behind the staged window)
+#define SCR_Q 0       // [2 x RN_BAND_QSTRIDE] band products in the layout of RnTablesDev::band_q: over the staged window, which
+                      //        is dead once the transform has its inputs; two arrays for the Ep / Exp pair
 #define SCR_EX 2336   // [32]  band energies of X: the one vector that lives from the first transform to the features
-#define SCR_MISC 2012 // sums[40] | Ep[32] | Exp[32] | Ly[32]: transform phases only (behind the band products)
+#define SCR_MISC 2092 // sums[2][40] | Ep[32] | Exp[32] | Ly[32]: transform phases only (behind the band products)
 
 // ---------------------------------------------------------------------------------------------
 // K1: rnn_compute_frame_features (src/denoise.c:347-398) on the high-passed frame that K0 put
@@ -440,6 +519,8 @@ struct AnalysisLds {
 // instructions and time).  Stop points sit where all waves of a workgroup pass together.
 #if RN_INSTRUMENT
 #define K1_STOP(k) do { if (k1_stop == (k)) return; } while (0)
+#elif defined(RN_K1_MARKS)  // tools/asm_sections.py: section boundaries as comments in the assembly (analysis builds only)
+#define K1_STOP(k) asm volatile("; K1MARK %0" ::"n"(k))
 #else
 #define K1_STOP(k) do { } while (0)
 #endif
@@ -449,6 +530,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const int slot = slot_arg & 255;
   const int k1_stop = RN_INSTRUMENT ? (slot_arg >> 16) : 0;
   (void)k1_stop;
+  // Which wave of the workgroup runs which narrow phase (see below).  Bit 9 of the slot argument: the four phases go to four
+  // DIFFERENT waves, rotated from workgroup to workgroup by a hash of the block number -- the extra work is then spread over
+  // the waves (and so over the SIMDs: a workgroup's waves sit on different SIMDs) instead of making wave 0 the straggler of
+  // every workgroup, and the two running-energy sweeps of phase 3 advance side by side.  Clear: everything on wave 0 (round 3).
+  const bool spread = SPW > 1 && (slot_arg & 512);
+  const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
+  const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw);
@@ -467,7 +555,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   } while (0)
   float *scr = L.a;
   float *xlp = scr + SCR_XLP, *Qs = scr + SCR_Q;
-  float *sums = scr + SCR_MISC, *Ex = scr + SCR_EX, *Ep = sums + 40, *Exp = Ep + 32, *Ly = Exp + 32;
+  float *sums = scr + SCR_MISC, *Ex = scr + SCR_EX, *Ep = sums + 80, *Exp = Ep + 32, *Ly = Exp + 32;
+  static_assert(SCR_Q + 2 * RN_BAND_QSTRIDE <= SCR_MISC && SCR_MISC + 80 + 96 <= SCR_MAIL, "transform-phase LDS map");
 #if RN_INSTRUMENT
   float *dbg = (g.debug && wr) ? g.debug + (size_t)s * RN_DBG_FLOATS : nullptr;
   unsigned long long clk_prev = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -477,12 +566,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   (void)clk_prev;
 #endif
   const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
-  auto pb_at = [&](int i) {  // pitch_buf[i], i in [0, 1728): ring0 + i < 2 * RN_RING_SIZE, one conditional wrap
-    int p = ring0 + i;
-    p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
-    return ring[p];
-  };
-#define PB(i) pb_at(i)
 
   CLK_TAP(0);
   CLK_TAP(1);
@@ -491,13 +574,23 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *S = scr;                             // [960] windowed frame in natural order (FFT phases only)
   // window [start, start+960) of pitch_buf -> this lane's 15 consecutive scaled samples (fft_reg.h "Input"), through LDS:
   // the global loads stay coalesced, and the 15-float runs are read back conflict-free (stride 15 is odd)
+  // (`start` wave-uniform.  All 30 loads are in flight together; the ring position wraps at most once inside a window, which
+  // an unsigned minimum resolves -- a - SIZE is huge when a < SIZE -- and which half of the window a sample is in is known
+  // at compile time for every t but one)
   auto window_to_regs = [&](float (&ar)[15], float (&ai)[15], int start, const float *hw) {
-#pragma unroll 5
-    for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {  // constant trip count: HBM/L2 round trips overlap 5 x 3 at a time
-      const int i = lane + WAVE * t;
-      const float w = hw[i < RN_FRAME_SIZE ? i : RN_WINDOW_SIZE - 1 - i];
-      S[i] = PB(start + i) * w;
+    int p0 = ring0 + start;
+    p0 = (p0 >= RN_RING_SIZE) ? p0 - RN_RING_SIZE : p0;
+    const unsigned pl = (unsigned)p0 + (unsigned)lane;
+    float v[RN_WINDOW_SIZE / WAVE], w[RN_WINDOW_SIZE / WAVE];
+#pragma unroll
+    for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {
+      const unsigned a = pl + WAVE * t;
+      v[t] = ring[min(a, a - (unsigned)RN_RING_SIZE)];
+      const unsigned i = (unsigned)lane + WAVE * t;
+      w[t] = hw[WAVE * t + WAVE <= RN_FRAME_SIZE ? i : (WAVE * t >= RN_FRAME_SIZE || i >= RN_FRAME_SIZE ? RN_WINDOW_SIZE - 1 - i : i)];
     }
+#pragma unroll
+    for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) S[lane + WAVE * t] = v[t] * w[t];
     RN_WSYNC();
     const float *run = S + 15 * fft_lam(lane);
 #pragma unroll
@@ -526,7 +619,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const int bin = WAVE * j + pos;
       if (bin < RN_FREQ_SIZE && wr) reinterpret_cast<float2 *>(gX)[bin] = make_float2(xr[j], xi[j]);
     }
-    band_products(Qs, xr, xi, xr, xi, tb, pos);
+    band_products<1>(Qs, xr, xi, xr, xi, tb, pos, lane);
   }
   band_chain(Ex, Qs, sums, tb, lane);
 
@@ -536,7 +629,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 #pragma unroll 7
   for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
     const int i0 = lane + WAVE * t, i = i0 < 864 ? i0 : 863;  // clamp, not a branch
-    const float a = PB(i ? 2 * i - 1 : 0), b = PB(2 * i), c = PB(2 * i + 1);
+    // pitch_buf[2i] sits at an even ring position, so {b, c} is one aligned 8-byte load that never straddles the wrap; the
+    // left neighbour may (sample 0 has none: its load is aimed at a valid address and dropped)
+    const unsigned pe = (unsigned)ring0 + 2u * (unsigned)i, pl_ = (unsigned)max((int)pe - 1, ring0);
+    const float2 bc = *reinterpret_cast<const float2 *>(ring + min(pe, pe - (unsigned)RN_RING_SIZE));
+    const float a = ring[min(pl_, pl_ - (unsigned)RN_RING_SIZE)], b = bc.x, c = bc.y;
     float v = .5f * (.5f * (a + c) + b);
     if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
     xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
@@ -622,7 +719,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
   if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
   WG_SYNC();
-  if (wave == 0) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
+  if (wave == nw1) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
     // The other waves of the workgroup wait for this one, and its chains are dependent instructions: it takes every issue
     // slot it can use (a lone wave issues once per ~5 cycles whatever its priority; profiles/r3_valu_issue.txt) ahead of the
     // three waves of other workgroups on its SIMD, which have independent work for the remaining slots.
@@ -649,7 +746,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   K1_STOP(8);
   WG_SYNC();
-  if (wave == 0) {
+  if (wave == nw2) {
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
     // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
     // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch
@@ -673,6 +770,21 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     RN_WSYNC();
     CLK_TAP(6);  // fine xcorr (+ the two start energies) of the whole workgroup (wave 0's view)
+    if (spread) __builtin_amdgcn_s_setprio(1);
+  }
+  if (spread) {
+    // narrow phase 3, spread: the fine running energy of every stream on one wave, yy_lookup of every stream on another
+    __syncthreads();
+    if (wave == nw3a || wave == nw3b) {
+      __builtin_amdgcn_s_setprio(3);
+      if (lane < SPW) {
+        float *a = arenas[lane].a;
+        if (wave == nw3a) sweep_syy_fine(a + SCR_D, a[SCR_MAIL + MAIL_SYY0F]);
+        else sweep_yy_lookup(a + SCR_SQ, a[SCR_MAIL + MAIL_XX]);
+      }
+      __builtin_amdgcn_s_setprio(1);
+    }
+  } else if (wave == 0) {
     // narrow phase 3: two lanes per stream -- the fine running energy and yy_lookup
     {
       const int gq = lane >> 1, role = lane & 1;
@@ -749,7 +861,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     K1_STOP(11);
     // Every dot product the decision loop can ask for, in ONE pass of 480-step chains on the first 32 lanes (each chain
     // is an independent serial sum, so computing it speculatively changes no bit):
-    //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  lanes 30, 31: the -1 / +1 neighbours of T0,
+    //   chain 1: xy(T0);  chains 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  chains 30, 31: the -1 / +1 neighbours of T0,
     //   which the final 3-point refinement (pitch.c:511-512) needs when no shorter period wins.
     //   (xx, the chain at offset 0, came out of energy_sweeps)
     // The neighbours of a shorter period T1(k) are fetched by a second, two-lane pass only when such a k wins.  (Round 2 ran
@@ -757,21 +869,25 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // 2,860 LDS cycles per frame, half of them conflicts, a third of the whole kernel's; 31 lanes fill one 32-lane access
     // group and leave the other empty.)
     {
+      // chain c = 1..31 (the numbering above) runs on lane c/2 of the first 32-lane LDS access group when c is even and on lane
+      // 32 + c/2 of the second when it is odd: the 8-byte operand reads of a group then come from 15 or 16 unrelated offsets
+      // instead of 31 (62 of the 64 banks wanted by one access: 32 % of the section's LDS cycles were conflicts)
+      const int c = (lane < 16) ? 2 * lane : ((lane >= 32 && lane < 48) ? 2 * (lane - 32) + 1 : 0);
       int off = -1;
-      if (lane == 1) off = T0;
-      else if (lane >= 2 && lane < 30) {
-        int k = 2 + ((lane - 2) >> 1);
+      if (c == 1) off = T0;
+      else if (c >= 2 && c < 30) {
+        int k = 2 + ((c - 2) >> 1);
         int T1 = (2 * T0 + k) / (2 * k), T1b;
         if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
         else T1b = (2 * sc[k] * T0 + k) / (2 * k);
-        off = ((lane - 2) & 1) ? T1b : T1;
-      } else if (lane == 30 || lane == 31) {
-        off = T0 + ((lane & 1) ? 1 : -1);
+        off = ((c - 2) & 1) ? T1b : T1;
+      } else if (c == 30 || c == 31) {
+        off = T0 + ((c & 1) ? 1 : -1);
         if (off < 0) off = 0;
       }
       if (off >= 0) {
         const int a = maxperiod - off;  // y = x_lp + a
-        dots[lane] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
+        dots[c] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
       }
     }
     RN_WSYNC();
@@ -863,7 +979,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const float2 *ftw2 = ftw;
     int lane2 = lane;
     asm volatile("" : "+s"(hw2), "+s"(ftw2), "+v"(lane2));
-    window_to_regs(pr, pi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - pitch_index, hw2);
+    window_to_regs(pr, pi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - __builtin_amdgcn_readfirstlane(pitch_index), hw2);
     // X is read back from HBM/L2 (this wave wrote it; its stores are long complete), in the lane-owns-bins layout
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -883,11 +999,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const int bin = WAVE * j + pos;
       if (bin < RN_FREQ_SIZE && wr) reinterpret_cast<float2 *>(gP)[bin] = make_float2(pr[j], pi[j]);
     }
-    band_products(Qs, pr, pi, pr, pi, tb, pos);
-    band_chain(Ep, Qs, sums, tb, lane);
-    band_products(Qs, xr, xi, pr, pi, tb, pos);
+    band_products<2>(Qs, xr, xi, pr, pi, tb, pos, lane);  // <P, P> and <X, P> side by side
   }
-  band_chain(Exp, Qs, sums, tb, lane);
+  band_sums<2>(sums, Qs, tb, lane);
+  if (lane < RN_NB_BANDS) {
+    Ep[lane] = band_of_sums(sums, lane);
+    Exp[lane] = band_of_sums(sums + 40, lane);
+  }
+  RN_WSYNC();
   K1_STOP(16);
   float *gE = g.spec_E[parity] + (size_t)s * 96;
   if (lane < RN_NB_BANDS) {
@@ -916,13 +1035,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   {
     float logMax = -2, follow = -2;
     for (int i = 0; i < RN_NB_BANDS; i++) {
-      float ly = Ly[i];
+      // (the reference's MAX16 / MIN16 ternaries as v_max_f32: the same value for every non-NaN operand pair -- at most the sign
+      //  of a zero differs, when +0 meets -0, which neither log10 nor these differences produce -- and one instruction instead
+      //  of a compare, a select and the VCC wait between them on this 32-step dependent chain)
       const float fd = follow - 1.5f;
-      const float t = (fd > ly) ? fd : ly;
-      const float lm7 = logMax - 7;
-      ly = (lm7 > t) ? lm7 : t;
-      logMax = (logMax > ly) ? logMax : ly;
-      follow = (fd > ly) ? fd : ly;
+      const float ly = fmaxf(logMax - 7, fmaxf(fd, Ly[i]));
+      logMax = fmaxf(logMax, ly);
+      follow = fmaxf(fd, ly);
       E += Ex[i];
       if (lane == 0) Ly[i] = ly;
     }
@@ -975,7 +1094,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 #pragma unroll
       for (int j = 0; j < 8; j++)
         if (WAVE * j + pos >= lp) yr[j] = yi[j] = 0.f;
-      band_products(Qs, yr, yi, yr, yi, tb, pos);
+      band_products<1>(Qs, yr, yi, yr, yi, tb, pos, lane);
     }
     band_chain(Ey, Qs, sums, tb, lane);
     if (lane < RN_NB_BANDS) {
@@ -990,7 +1109,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
   }
   CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
-#undef PB
 }
 
 // (4 waves per SIMD is what the LDS allows: 16 arenas of 10 KB per CU; without the cap the allocator spreads to 154 VGPRs)
@@ -1025,7 +1143,7 @@ struct SynthLds {
 };
 // 4,976 B: two of these waves fit into the LDS that four analysis workgroups (4 x 38,016 B) leave free on a CU -- with the
 // complex spectrum staged in one piece (8,448 B) it was one, and synthesis mostly waited for analysis workgroups to drain
-static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052, "synthesis LDS");
+static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTRIDE <= 1052, "synthesis LDS");
 
 // ---------------------------------------------------------------------------------------------
 // K3: rnn_pitch_filter + gain smoothing/interpolation + frame_synthesis
@@ -1068,6 +1186,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     bq[j] = (bin < 400) ? tb.band_q[bin] : 0u;
     frac[j] = (bin < 400) ? tb.band_frac[bin] : 0.f;
   }
+  const int pad_slot = tb.band_pad[lane];  // (band_sums: the pad floats of the product array hold +0.0f)
   float e_ex = 0, e_ep = 0, e_exp = 0, c_ex = 0, gi = 0, lastg = 0;
   if (lane < RN_NB_BANDS && !silence) {
     e_ex = dE[lane]; e_ep = dE[32 + lane]; e_exp = dE[64 + lane]; c_ex = cE[lane];
@@ -1107,6 +1226,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       rv = (float)((double)rv * sqrt((double)e_ex / (1e-8 + (double)e_ep)));
       r[lane] = rv;
     }
+    Q[pad_slot] = 0.f;
     RN_WSYNC();
 #pragma unroll
     for (int j = 0; j < NBIN; j++) {  // :441-445, then the products of compute_band_energy (:446)
@@ -1206,7 +1326,9 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
     static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
     static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop, parity);
+    // narrow phases spread over the waves of a workgroup (analysis_body); RNNOISE_AMD_K1_SPREAD=0: all on wave 0 (A/B runs)
+    static const int spread = [] { const char *e = getenv("RNNOISE_AMD_K1_SPREAD"); return (e && atoi(e) == 0) ? 0 : 512; }();
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread, parity);
   }
   return hipGetLastError();
 }

@@ -20,6 +20,9 @@
 #endif
 #include "../../include/rn_layout.h"
 
+// floats of one band-product array in LDS (the layout of RnTablesDev::band_q, shim.cpp: tables_for_device); the analysis
+// kernel forms two band vectors at once from two arrays this far apart
+#define RN_BAND_QSTRIDE 1044
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
 // spectra slots: frame t writes slot t%3, synthesis of frame t reads slots t%3 (Ex) and (t-1)%3 (the
 // reference's delayed_*); the third slot lets the analysis of frame t+1 run beside synthesis of frame t
@@ -44,6 +47,8 @@ struct RnTablesDev {
   const float *fft_tw;        // [16][64][2] per-lane twiddles of the register-resident FFT (fft_reg.h: RN_FTW_*)
   const uint32_t *band_q;     // [400]  per bin: LDS slot of its (1-frac) term | slot of its frac term << 11 | band << 22
   const uint32_t *band_chain; // [34]   per band accumulator: first slot (16-byte aligned) | number of terms << 16
+  const uint16_t *band_pad;   // [64]   the floats behind an accumulator's last term up to the end of its last 16-byte slot
+                              //        (48 of them; the table repeats the last): they hold +0.0f while the sums are formed
   double dct_scale;           // sqrt(2./22), src/denoise.c:168
 };
 

@@ -452,6 +452,7 @@ int tables_for_device(int device, RnTablesDev &out) {
   // serial sum reads them four at a time.  band_q[bin] = address of the (1-frac) term | address of the frac term << 11 |
   // band << 22;  band_chain[k] = start | length << 16.
   std::vector<uint32_t> band_q(400), band_chain(RN_NB_BANDS + 2);
+  std::vector<uint16_t> band_pad(64);
   {
     int start[RN_NB_BANDS + 2], lo[RN_NB_BANDS + 2], pos = 0;
     // Lane k sums accumulator k with 16-byte reads.  ds_read_b128 serves a wave in four groups of 16 lanes
@@ -473,9 +474,26 @@ int tables_for_device(int device, RnTablesDev &out) {
       band_chain[k] = (uint32_t)pos | ((uint32_t)len << 16);
       pos += (len + 3) & ~3;
     }
-    if (pos > 1052) {  // SCR_Q .. SCR_MISC of the analysis arena (dsp_kernels.hip)
+    if (pos > RN_BAND_QSTRIDE) {  // one product array of the analysis / synthesis kernels (dsp_kernels.hip)
       fprintf(stderr, "[rnnoise_amd] band-sum layout needs %d floats\n", pos);
       return -1;
+    }
+    // The serial sums read whole 16-byte slots: the 1..3 floats between an accumulator's last term and the end of its last
+    // slot hold +0.0f (adding it changes no bit), written by the first lanes of the wave before every use -- band_pad[lane]
+    // = the lane's pad float (there are 48; the remaining lanes rewrite the last one).
+    {
+      int np = 0;
+      for (int k = 0; k < RN_NB_BANDS + 2; k++) {
+        const int len = (int)(band_chain[k] >> 16), st0 = (int)(band_chain[k] & 0xffff);
+        for (int i = len; i < ((len + 3) & ~3); i++) {
+          if (np >= 64) {
+            fprintf(stderr, "[rnnoise_amd] band-sum layout has more than 64 pad floats\n");
+            return -1;
+          }
+          band_pad[np++] = (uint16_t)(st0 + i);
+        }
+      }
+      for (int i = np; i < 64; i++) band_pad[i] = band_pad[np - 1];
     }
     for (int b = 0; b <= RN_NB_BANDS; b++)
       for (int bin = kEband[b]; bin < kEband[b + 1]; bin++)
@@ -484,7 +502,8 @@ int tables_for_device(int device, RnTablesDev &out) {
   if (rcp_ensure_locked()) return -1;
   Staging st;
   size_t o_ftw = st.add(ftw.data(), 4 * ftw.size());
-  size_t o_bq = st.add(band_q.data(), 4 * band_q.size()), o_bc = st.add(band_chain.data(), 4 * band_chain.size());
+  size_t o_bq = st.add(band_q.data(), 4 * band_q.size()), o_bc = st.add(band_chain.data(), 4 * band_chain.size()),
+         o_bp = st.add(band_pad.data(), 2 * band_pad.size());
   size_t o_w = st.add(window.data(), 4 * window.size()), o_d = st.add(dct.data(), 4 * dct.size()),
          o_t = st.add(tw.data(), 4 * tw.size()), o_f = st.add(frac.data(), 4 * frac.size()),
          o_b = st.add(band_of.data(), band_of.size()), o_r = st.add(g_rcp.t, sizeof g_rcp.t),
@@ -505,6 +524,7 @@ int tables_for_device(int device, RnTablesDev &out) {
   t.dev.fft_tw = reinterpret_cast<const float *>(base + o_ftw);
   t.dev.band_q = reinterpret_cast<const uint32_t *>(base + o_bq);
   t.dev.band_chain = reinterpret_cast<const uint32_t *>(base + o_bc);
+  t.dev.band_pad = reinterpret_cast<const uint16_t *>(base + o_bp);
   t.dev.dct_scale = sqrt(2. / 22);
   g_tables.push_back(t);
   out = t.dev;
