@@ -1,0 +1,512 @@
+// dropin.cpp -- the reference's own API (include/rnnoise.h; reference implementation src/denoise.c:227-325,457-504) on
+// device-resident state pools, and the combiner that turns concurrent one-frame calls into shared launches.
+#include "shim.h"
+
+#include <linux/futex.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// device-resident one-stream states (rnnoise_create / rnnoise_destroy)
+// ---------------------------------------------------------------------------------------------
+StatePool *pool_new(RNNModel *model, int device) {
+  StatePool *p = new StatePool();
+  p->batch = rnnoise_batch_create(model, StatePool::POOL_SLOTS, device);
+  if (!p->batch) {
+    delete p;
+    return nullptr;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok ||
+      hipHostMalloc((void **)&p->h_io, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&p->d_flat, (size_t)StatePool::POOL_SLOTS * StatePool::FLAT_BLK * sizeof(float)) != hipSuccess) {
+    if (p->h_io) hipHostFree(p->h_io);
+    rnnoise_batch_destroy(p->batch);
+    delete p;
+    return nullptr;
+  }
+  memset(p->h_io, 0, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float));
+  return p;
+}
+
+// a free row of one of the model's pools on device 0 (a new pool when all are full); zeroed like rnnoise_init()
+int pool_acquire(RNNModel *model, StatePool *&pool, int &slot) {
+  std::unique_lock<std::mutex> lk(model->mu);
+  for (int pass = 0; pass < 2; pass++) {
+    for (StatePool *p : model->pools) {
+      std::lock_guard<std::mutex> pl(p->mu);
+      if (~p->used) {
+        slot = __builtin_ctzll(~p->used);
+        p->used |= 1ull << slot;
+        pool = p;
+        return 0;
+      }
+    }
+    if (pass == 0) {
+      lk.unlock();  // rnnoise_batch_create takes the model lock itself
+      StatePool *p = pool_new(model, 0);
+      lk.lock();
+      if (!p) return -1;
+      model->pools.push_back(p);
+    }
+  }
+  return -1;
+}
+
+void pool_release(StatePool *p, int slot) {
+  std::lock_guard<std::mutex> pl(p->mu);
+  p->used &= ~(1ull << slot);
+}
+
+// the stateful arrays of one row back to all-zero (what rnnoise_init does to a DenoiseState, src/denoise.c:286)
+int pool_zero_row(StatePool *p, int slot, hipStream_t st) {
+  const RnGroupDev v = group_view(p->batch->g, slot, 1);
+  const size_t N = p->batch->n;
+  HIP_OK(hipMemsetAsync(v.mem_hp, 0, 2 * 4, st));
+  HIP_OK(hipMemsetAsync(v.pitch_ring, 0, RN_RING_SIZE * 4, st));
+  HIP_OK(hipMemsetAsync(v.synth_mem, 0, RN_FRAME_SIZE * 4, st));
+  HIP_OK(hipMemsetAsync(v.last_gain, 0, 4, st));
+  HIP_OK(hipMemsetAsync(v.last_period, 0, 4, st));
+  HIP_OK(hipMemsetAsync(v.lastg, 0, RN_NB_BANDS * 4, st));
+  HIP_OK(hipMemsetAsync(v.conv1_state, 0, 130 * 4, st));
+  HIP_OK(hipMemsetAsync(v.conv2_state, 0, 256 * 4, st));
+  for (int k = 0; k < 3; k++) HIP_OK(hipMemsetAsync(v.gru_state + k * N * RN_GRU, 0, RN_GRU * 4, st));
+  for (int k = 0; k < RN_SPEC_SLOTS; k++) {
+    HIP_OK(hipMemsetAsync(v.spec_X[k], 0, RN_SPEC_STRIDE * 4, st));
+    HIP_OK(hipMemsetAsync(v.spec_P[k], 0, RN_SPEC_STRIDE * 4, st));
+    HIP_OK(hipMemsetAsync(v.spec_E[k], 0, 96 * 4, st));
+  }
+  return 0;
+}
+
+// one frame of one row: the four kernels of a step on a one-stream view, on `st` (no side streams: a single frame has
+// nothing to overlap with).  The row's frame bookkeeping (parity, ring slot, scratch copy) is the caller's.
+int pool_step(StatePool *p, int slot, int parity, int ring_slot, long frame_no, float *d_out, const float *d_in, float *d_vad,
+              hipStream_t st) {
+  RNNoiseBatch *b = p->batch;
+  RnGroupDev g = group_view(b->g, slot, 1);
+  if (frame_no & 1) {
+    g.features = g.features_b;
+    g.silence = g.silence_b;
+    g.pitch = g.pitch_b;
+  }
+  g.vad = d_vad;
+  const int prev = (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
+  HIP_OK(rn_launch_hp(&g, d_in, 0, ring_slot, st, nullptr, nullptr));
+  HIP_OK(rn_launch_analysis(&g, &b->tb, ring_slot, parity, st, nullptr, nullptr));
+  if (nn_one_max_streams() >= 1) HIP_OK(rn_launch_nn_one(&g, &b->m, &b->tb, st, nullptr, nullptr));
+  else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, nullptr, nullptr));
+  HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out, 0, parity, prev, st, nullptr, nullptr));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The combiner.  rnnoise_process_frame is one frame of one stream, synchronous (include/rnnoise.h:94); a frame is four
+// dependent kernels of one workgroup each, ~110 us of GPU latency during which the GPU is all but idle, and HIP streams are
+// multiplexed onto four hardware queues -- so T threads with a stream per state got the throughput of four (round 3: 24.9 k
+// frames/s from sixteen threads).  Here the states of a pool share launches instead: a caller queues its request (row, frame
+// phase; the frame itself is already in the row's pinned block) and
+//   * if a stream is free, takes everything queued as ONE group: the four latency kernels over the row list (rn_dev.h:
+//     RnRows, carried in the kernel arguments), waits for the stream, marks every member done and wakes the sleepers;
+//   * otherwise waits on its request's state word -- spinning while there are cores to spin on, a futex after that;
+//   * the caller that completes a group launches the next one for whoever queued up meanwhile and names one of ITS members
+//     to wait for it, so the GPU never waits for a sleeping thread to be scheduled;
+//   * the threads of a group that has just completed come back within microseconds of each other: the first one back holds
+//     its launch for at most $RNNOISE_AMD_COMBINE_GATHER_US (15) until the others have queued too -- without that, T threads
+//     in lock-step decay into T one-row launches and one big group that waits a whole frame time for a stream.
+// One thread alone takes the first branch at once, every time: its latency is the four kernels', as before.
+// ---------------------------------------------------------------------------------------------
+enum : int { REQ_IDLE = 0, REQ_QUEUED, REQ_INFLIGHT, REQ_SYNCER, REQ_DONE_OK, REQ_DONE_FAIL };
+
+uint64_t now_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+// CPUs this process may actually run on: the affinity mask, cut down to the cgroup's CPU quota (a container with 16 CPUs of
+// quota on a 128-thread host can keep 16 threads spinning, not 128)
+int effective_cpus() {
+  static const int n = [] {
+    int cpus = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus, CPU_COUNT(&set));
+    long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+      char q[32] = "";
+      if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max")) quota = atol(q);
+      fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+      if (fscanf(f1, "%ld", &quota) != 1) quota = -1;
+      fclose(f1);
+      if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(f2, "%ld", &period) != 1) period = -1;
+        fclose(f2);
+      }
+    }
+    if (quota > 0 && period > 0) cpus = std::min<long>(cpus, std::max<long>(1, (quota + period - 1) / period));
+    return std::max(1, cpus);
+  }();
+  return n;
+}
+long futex(int *addr, int op, int val) { return syscall(SYS_futex, addr, op, val, nullptr, nullptr, 0); }
+
+// publish a request's new state; wake its owner if it went to sleep on the word
+void req_set(PooledRef *m, int state) {
+  __atomic_store_n(&m->req, state, __ATOMIC_SEQ_CST);
+  if (__atomic_load_n(&m->sleeping, __ATOMIC_SEQ_CST)) futex(&m->req, FUTEX_WAKE_PRIVATE, 1);
+}
+
+int comb_free_stream(StatePool *p) {  // (lock held) a stream without a group in flight, created on demand; -1: none
+  Combiner &c = p->comb;
+  static const int max_streams = std::max(1, std::min((int)Combiner::MAXG, env_int("RNNOISE_AMD_COMBINE_STREAMS", 3)));
+  for (int k = 0; k < c.n_streams; k++)
+    if (!c.busy[k]) return k;
+  if (c.n_streams < max_streams) {
+    if (hipStreamCreateWithFlags(&c.stream[c.n_streams], hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    return c.n_streams++;
+  }
+  return -1;
+}
+
+// the four kernels of one frame step over the rows of `grp`, on stream k of the pool's combiner
+int comb_launch(StatePool *p, int k, const std::vector<PooledRef *> &grp) {
+  RNNoiseBatch *b = p->batch;
+  RnRows rows;
+  rows.io = p->h_io;  // (pinned host memory is mapped into the device's address space at the same address)
+  rows.n = (int)grp.size();
+  for (int i = 0; i < rows.n; i++)
+    rows.e[i] = (uint32_t)grp[i]->slot | ((uint32_t)grp[i]->ring_slot << 8) | ((uint32_t)grp[i]->parity << 12);
+  for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
+  hipStream_t st = p->comb.stream[k];
+  HIP_OK(rn_launch_hp_rows(&b->g, &rows, st));
+  HIP_OK(rn_launch_analysis_rows(&b->g, &b->tb, &rows, st));
+  HIP_OK(rn_launch_nn_rows(&b->g, &b->m, &b->tb, &rows, st));
+  HIP_OK(rn_launch_synthesis_rows(&b->g, &b->tb, &rows, st));
+  return 0;
+}
+
+// The caller `self` owns the wait for the group on stream k (it launched it, or was named its syncer): wait, hand the stream
+// to whatever queued up meanwhile, publish the results.  Returns self's own result.
+bool comb_complete(StatePool *p, int k, PooledRef *self) {
+  Combiner &c = p->comb;
+  const bool ok = hipStreamSynchronize(c.stream[k]) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  std::vector<PooledRef *> done, next;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    done.swap(c.members[k]);
+    if (!c.queue.empty() && !c.gathering) {
+      next.swap(c.queue);
+      for (PooledRef *m : next) {
+        m->grp = k;
+        __atomic_store_n(&m->req, REQ_INFLIGHT, __ATOMIC_SEQ_CST);
+      }
+      c.members[k] = next;
+    } else {
+      c.busy[k] = false;
+    }
+    c.pending_returns.store((int)done.size(), std::memory_order_relaxed);
+    c.t_complete_ns.store(now_ns(), std::memory_order_relaxed);
+  }
+  for (PooledRef *m : done)
+    if (m != self) req_set(m, ok ? REQ_DONE_OK : REQ_DONE_FAIL);
+  if (!next.empty()) {
+    if (comb_launch(p, k, next) == 0) {
+      req_set(next[0], REQ_SYNCER);  // one of its own members waits for it
+    } else {
+      {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.members[k].clear();
+        c.busy[k] = false;
+      }
+      (void)hipStreamSynchronize(c.stream[k]);  // whatever part of the group was launched must not outlive its frames
+      for (PooledRef *m : next) req_set(m, REQ_DONE_FAIL);
+    }
+  }
+  return ok;
+}
+
+// one frame of a pooled state through the combiner: r->h_io holds the input; true when out / vad are in place
+bool comb_submit(StatePool *p, PooledRef *r) {
+  Combiner &c = p->comb;
+  static const uint64_t gather_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_GATHER_US", 15)) * 1000ull;
+  static const int spin_us = env_int("RNNOISE_AMD_COMBINE_SPIN_US", 400);
+  struct Active {
+    std::atomic<int> &a;
+    explicit Active(std::atomic<int> &a_) : a(a_) { a.fetch_add(1, std::memory_order_relaxed); }
+    ~Active() { a.fetch_sub(1, std::memory_order_relaxed); }
+  } active(c.active);
+  int lead = -1;
+  std::vector<PooledRef *> grp;
+  {
+    std::unique_lock<std::mutex> lk(c.mu);
+    if (c.pending_returns.load(std::memory_order_relaxed) > 0) c.pending_returns.fetch_sub(1, std::memory_order_relaxed);
+    __atomic_store_n(&r->req, REQ_QUEUED, __ATOMIC_SEQ_CST);
+    c.queue.push_back(r);
+    int k = c.gathering ? -1 : comb_free_stream(p);
+    if (k >= 0 && c.pending_returns.load(std::memory_order_relaxed) > 0 && gather_ns) {
+      // the other threads of the group that has just completed are on their way back: hold the stream for them
+      c.gathering = true;
+      lk.unlock();
+      while (c.pending_returns.load(std::memory_order_relaxed) > 0 && now_ns() - c.t_complete_ns.load(std::memory_order_relaxed) < gather_ns)
+        cpu_relax();
+      lk.lock();
+      c.gathering = false;
+      c.pending_returns.store(0, std::memory_order_relaxed);
+      k = comb_free_stream(p);
+    }
+    if (k >= 0 && __atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == REQ_QUEUED) {  // lead: the whole queue is this group
+      grp.swap(c.queue);
+      c.busy[k] = true;
+      c.members[k] = grp;
+      for (PooledRef *m : grp) {
+        m->grp = k;
+        __atomic_store_n(&m->req, REQ_INFLIGHT, __ATOMIC_SEQ_CST);
+      }
+      lead = k;
+    }
+  }
+  if (lead >= 0) {
+    if (comb_launch(p, lead, grp)) {
+      {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.members[lead].clear();
+        c.busy[lead] = false;
+      }
+      (void)hipStreamSynchronize(c.stream[lead]);  // whatever part of the group was launched must not outlive its frames
+      for (PooledRef *m : grp)
+        if (m != r) req_set(m, REQ_DONE_FAIL);
+      return false;
+    }
+    return comb_complete(p, lead, r);
+  }
+  // wait for the request's state word: done (by the group's owner), or this thread is named the owner of its group's wait
+  const bool may_spin = c.active.load(std::memory_order_relaxed) <= effective_cpus();
+  const uint64_t spin_until = now_ns() + (uint64_t)(may_spin ? spin_us : 20) * 1000ull;
+  for (unsigned it = 0;; it++) {
+    const int s = __atomic_load_n(&r->req, __ATOMIC_SEQ_CST);
+    if (s == REQ_DONE_OK) return true;
+    if (s == REQ_DONE_FAIL) return false;
+    if (s == REQ_SYNCER) return comb_complete(p, r->grp, r);
+    if ((it & 63) != 63 || now_ns() < spin_until) {
+      cpu_relax();
+      continue;
+    }
+    __atomic_store_n(&r->sleeping, 1, __ATOMIC_SEQ_CST);
+    if (__atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == s) futex(&r->req, FUTEX_WAIT_PRIVATE, s);
+    __atomic_store_n(&r->sleeping, 0, __ATOMIC_SEQ_CST);
+  }
+}
+
+}  // namespace
+
+void pools_free(RNNModel *model) {
+  for (StatePool *p : model->pools) {
+    {
+      DeviceGuard guard(p->batch->device);
+      for (int k = 0; k < p->comb.n_streams; k++) {
+        hipStreamSynchronize(p->comb.stream[k]);
+        hipStreamDestroy(p->comb.stream[k]);
+      }
+      hipHostFree(p->h_io);
+      hipFree(p->d_flat);
+    }
+    rnnoise_batch_destroy(p->batch);
+    delete p;
+  }
+  model->pools.clear();
+}
+
+extern "C" int rnnoise_get_size(void) { return (int)sizeof(DenoiseState); }
+extern "C" int rnnoise_get_frame_size(void) { return RN_FRAME_SIZE; }
+
+// rnnoise_init() on caller-owned memory (include/rnnoise.h:57,71): there is no rnnoise_uninit, so such a state must not
+// hold library resources -- it stays a self-contained POD and is staged to a pool row for every frame.
+extern "C" int rnnoise_init(DenoiseState *st, RNNModel *model) {
+  if (!st) return -1;
+  memset(st, 0, sizeof *st);
+  if (!model && !(model = default_model())) return -1;
+  {
+    std::lock_guard<std::mutex> lk(model->mu);
+    if (model_parse_locked(model)) return -1;
+  }
+  if (rnnoise_amd_device_count() < 1) {
+    fprintf(stderr, "[rnnoise_amd] no HIP device visible; this library has no CPU path\n");
+    return -1;
+  }
+  st->magic = kStateMagic;
+  st->model = model;
+  return 0;
+}
+
+// rnnoise_create(): the state lives in HBM (a row of a StatePool) until rnnoise_destroy().
+extern "C" DenoiseState *rnnoise_create(RNNModel *model) {
+  if (!model && !(model = default_model())) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(model->mu);
+    if (model_parse_locked(model)) return nullptr;
+  }
+  if (rnnoise_amd_device_count() < 1) {
+    fprintf(stderr, "[rnnoise_amd] no HIP device visible; this library has no CPU path\n");
+    return nullptr;
+  }
+  DenoiseState *st = static_cast<DenoiseState *>(calloc(1, sizeof(DenoiseState)));
+  if (!st) return nullptr;
+  PooledRef &r = st->ref;
+  if (pool_acquire(model, r.pool, r.slot)) {
+    free(st);
+    return nullptr;
+  }
+  DeviceGuard guard(r.pool->batch->device);
+  r.mu = new std::mutex();
+  r.h_io = r.pool->h_io + (size_t)r.slot * RN_ROW_IO;
+  // (the row is cleared on the legacy default stream, which the pool's non-blocking streams do not synchronise with: the other
+  //  rows' frames are not held up)
+  if (!guard.ok || pool_zero_row(r.pool, r.slot, nullptr) || hipStreamSynchronize(nullptr) != hipSuccess) {
+    delete r.mu;
+    pool_release(r.pool, r.slot);
+    free(st);
+    return nullptr;
+  }
+  st->magic = kPooledMagic;
+  st->model = model;
+  return st;
+}
+
+extern "C" void rnnoise_destroy(DenoiseState *st) {
+  if (!st) return;
+  if (st->magic == kPooledMagic) {
+    PooledRef &r = st->ref;
+    if (r.stream) {
+      DeviceGuard guard(r.pool->batch->device);
+      hipStreamSynchronize(r.stream);
+      hipStreamDestroy(r.stream);
+    }
+    delete r.mu;
+    pool_release(r.pool, r.slot);
+  }
+  free(st);
+}
+
+// One 480-sample frame of one stream (include/rnnoise.h:94).  There is no error channel in this signature: on a GPU
+// failure the frame comes back zeroed with VAD 0 and the reason on stderr (the host process is never aborted).
+static float frame_failed(float *out, const char *why) {
+  fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: %s; returning a zeroed frame\n", why);
+  if (out) memset(out, 0, RN_FRAME_SIZE * sizeof(float));
+  return 0.f;
+}
+
+extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float *in) {
+  if (!st || (st->magic != kStateMagic && st->magic != kPooledMagic) || !st->model || !out || !in)
+    return frame_failed(out, "uninitialised state or NULL buffer");
+  if (st->magic == kPooledMagic) {
+    // device-resident state.  The frame travels through the row's block of the pool's pinned memory, which the kernels address
+    // directly (host memory mapped into the device's address space: the first kernel reads its 1,920 bytes over PCIe, the
+    // last ones write frame and VAD back): no copy commands.  The launches are shared with whoever else is calling on this
+    // pool right now (the combiner above); $RNNOISE_AMD_COMBINE=0: four launches on a stream of the state's own, as in
+    // round 3 (A/B runs).
+    PooledRef &r = st->ref;
+    std::lock_guard<std::mutex> lk(*r.mu);
+    DeviceGuard guard(r.pool->batch->device);
+    if (!guard.ok) return frame_failed(out, "cannot select the HIP device");
+    static const bool combine = [] { const char *e = getenv("RNNOISE_AMD_COMBINE"); return !e || atoi(e) != 0; }();
+    float *h_in = r.h_io, *h_out = r.h_io + RN_FRAME_SIZE + 4;
+    memcpy(h_in, in, RN_FRAME_SIZE * sizeof(float));
+    bool ok;
+    if (combine) {
+      ok = comb_submit(r.pool, &r);
+    } else {
+      ok = (r.stream || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess) &&
+           pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, h_out, h_in, h_out + RN_FRAME_SIZE, r.stream) == 0 &&
+           hipStreamSynchronize(r.stream) == hipSuccess;
+    }
+    if (!ok) return frame_failed(out, "GPU step failed");
+    r.parity = (r.parity + 1) % RN_SPEC_SLOTS;
+    r.ring_slot = (r.ring_slot + 1) % RN_RING_SLOTS;
+    r.frame_no++;
+    memcpy(out, h_out, RN_FRAME_SIZE * sizeof(float));
+    return h_out[RN_FRAME_SIZE];
+  }
+  // self-contained state: borrow a pool row for the duration of the call -- state + frame up in one copy, scatter,
+  // the four kernels, gather, state + frame + VAD down in one copy.  Rows are per call, so states on different threads
+  // proceed concurrently.
+  RNNModel *m = st->model;
+  StatePool *pool = nullptr;
+  int slot = -1;
+  if (pool_acquire(m, pool, slot)) return frame_failed(out, "no GPU state row available (no CPU fallback)");
+  struct Scratch {  // per-thread: a stream and a pinned staging block, created on first use, released at thread exit
+    hipStream_t stream = nullptr;
+    float *h = nullptr;
+    int device = -1;
+    bool ready(int dev) {  // both resources or neither: a half-built scratch is torn down and retried at the next call
+      if (stream && h && device == dev) return true;
+      release();
+      if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
+      if (hipHostMalloc((void **)&h, 2 * StatePool::FLAT_BLK * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        h = nullptr;
+        release();
+        return false;
+      }
+      device = dev;
+      return true;
+    }
+    void release() {
+      if (stream || h) {
+        DeviceGuard guard(device >= 0 ? device : 0);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (h) (void)hipHostFree(h);
+      }
+      stream = nullptr;
+      h = nullptr;
+      device = -1;
+    }
+    ~Scratch() { release(); }
+  };
+  static thread_local Scratch sc;
+  float vad = 0.f;
+  bool ok = false;
+  {
+    DeviceGuard guard(pool->batch->device);
+    constexpr size_t IO = StatePool::FLAT_IO, UP = IO + RN_FRAME_SIZE, DOWN = UP + 1;
+    if (guard.ok && sc.ready(pool->batch->device)) {
+      float *d_blk = pool->d_flat + (size_t)slot * StatePool::FLAT_BLK, *d_io = d_blk + IO;  // frame processed in place
+      const RnGroupDev v = group_view(pool->batch->g, slot, 1);
+      // conventions of a freshly scattered row: its newest frame sits in ring slot 5 and spectra slot 2, so the next frame
+      // goes to ring slot 0 / spectra slot 0 and leaves its own "delayed" spectra in slot 0
+      float *hu = sc.h, *hd = sc.h + StatePool::FLAT_BLK;
+      memcpy(hu, st->state, RN_STATE_FLOATS * sizeof(float));
+      memcpy(hu + IO, in, RN_FRAME_SIZE * sizeof(float));
+      ok = hipMemcpyAsync(d_blk, hu, UP * sizeof(float), hipMemcpyHostToDevice, sc.stream) == hipSuccess &&
+           rn_launch_state_scatter(&v, d_blk, RN_RING_SLOTS - 1, RN_SPEC_SLOTS - 1, sc.stream) == hipSuccess &&
+           pool_step(pool, slot, 0, 0, 0, d_io, d_io, d_io + RN_FRAME_SIZE, sc.stream) == 0 &&
+           rn_launch_state_gather(&v, d_blk, 0, 0, sc.stream) == hipSuccess &&
+           hipMemcpyAsync(hd, d_blk, DOWN * sizeof(float), hipMemcpyDeviceToHost, sc.stream) == hipSuccess &&
+           hipStreamSynchronize(sc.stream) == hipSuccess;
+      if (ok) {
+        memcpy(st->state, hd, RN_STATE_FLOATS * sizeof(float));
+        memcpy(out, hd + IO, RN_FRAME_SIZE * sizeof(float));
+        vad = hd[IO + RN_FRAME_SIZE];
+      }
+    }
+  }
+  pool_release(pool, slot);
+  if (!ok) return frame_failed(out, "GPU step failed");
+  return vad;
+}
+

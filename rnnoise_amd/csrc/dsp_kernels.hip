@@ -407,6 +407,51 @@ __device__ __forceinline__ float chain_dot8_y2(ldsf x, ldsf y2, int n) {
   return s;
 }
 
+// chain_dot8_y2 for a pass in which EVERY lane of the wave takes part and all chains share x (the doubling dots): the x
+// operand then does not come from LDS once per lane -- a ds_read_b128 of the same 16 bytes by 64 lanes costs 4 LDS cycles, as
+// much as the whole y operand, and these passes are bound by the LDS pipe -- but once per wave: each row of 16 lanes holds
+// x[i .. i+15] in one register (lane l: x[i + (l & 15)], one 4-byte read per 16 steps) and step k takes lane k of the row as a
+// DPP operand of the multiply (v_mul_f32_dpp row_newbcast:k).  Same products, same order of adds: the bits are chain_dot8_y2's.
+// A DPP operand reads the register of another LANE, which must be active: callers run this with all 64 lanes (lanes without a
+// chain of their own compute a dummy one).  n a multiple of 16.
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {  // lane K of each 16-lane row to every lane of the row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, true));
+}
+template <int K>
+struct ChainSteps {
+  static __device__ __forceinline__ void run(float &s, float xr, const v2f (&y)[8]) {
+    float p = row_bcast<K>(xr) * ((K & 1) ? y[K >> 1].y : y[K >> 1].x);
+    OPAQUE(p);
+    s = s + p;
+    ChainSteps<K + 1>::run(s, xr, y);
+  }
+};
+template <>
+struct ChainSteps<16> {
+  static __device__ __forceinline__ void run(float &, float, const v2f (&)[8]) {}
+};
+__device__ __forceinline__ float chain_dot16_xrow(ldsf x, ldsf y2, int n, int lane) {
+  float s = 0.f;
+  ldsf xl = x + (lane & 15);
+  float xr = *xl;
+  v2f ya[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) ya[k] = lds_read8(y2 + 2 * k);
+  for (int i = 0; i < n; i += 16) {
+    const int nx = (i + 16 < n) ? i + 16 : i;
+    const float xn = xl[nx];
+    v2f yn[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) yn[k] = lds_read8(y2 + nx + 2 * k);
+    ChainSteps<0>::run(s, xr, ya);
+    xr = xn;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ya[k] = yn[k];
+  }
+  return s;
+}
+
 // One 10 KB LDS arena per wave (16 waves = one full round per CU at 4096 streams), time-shared
 // (float offsets, the SCR_* constants below):
 //   FFT phases   : F = [0,2160) (960 complex, padded layout); the band products Q live in [1084,1948),
@@ -526,7 +571,7 @@ struct AnalysisLds {
 #endif
 template <bool TRAIN, int SPW>
 __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot_arg, int parity,
-                                              const RnTrainArgs &tr) {
+                                              const RnTrainArgs &tr, int listed_row = -1) {
   const int slot = slot_arg & 255;
   const int k1_stop = RN_INSTRUMENT ? (slot_arg >> 16) : 0;
   (void)k1_stop;
@@ -544,7 +589,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   AnalysisLds &L = arenas[wave];
   float *mail = L.a + SCR_MAIL;
   // a tail workgroup's surplus waves redo the last stream without storing anything: they still meet every barrier
-  const int s_raw = blockIdx.x * SPW + wave;
+  const int s_raw = listed_row >= 0 ? listed_row : (int)blockIdx.x * SPW + wave;  // (a listed row: rn_dev.h RnRows, one-stream workgroups)
   const bool wr = s_raw < g.n_streams;
   const int s = wr ? s_raw : g.n_streams - 1;
 // workgroup barrier between a stream's own wave and wave 0 (a wavefront fence when the workgroup is one wave)
@@ -861,7 +906,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     K1_STOP(11);
     // Every dot product the decision loop can ask for, in ONE pass of 480-step chains on the first 32 lanes (each chain
     // is an independent serial sum, so computing it speculatively changes no bit):
-    //   chain 1: xy(T0);  chains 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  chains 30, 31: the -1 / +1 neighbours of T0,
+    //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  lanes 30, 31: the -1 / +1 neighbours of T0,
     //   which the final 3-point refinement (pitch.c:511-512) needs when no shorter period wins.
     //   (xx, the chain at offset 0, came out of energy_sweeps)
     // The neighbours of a shorter period T1(k) are fetched by a second, two-lane pass only when such a k wins.  (Round 2 ran
@@ -869,26 +914,23 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // 2,860 LDS cycles per frame, half of them conflicts, a third of the whole kernel's; 31 lanes fill one 32-lane access
     // group and leave the other empty.)
     {
-      // chain c = 1..31 (the numbering above) runs on lane c/2 of the first 32-lane LDS access group when c is even and on lane
-      // 32 + c/2 of the second when it is odd: the 8-byte operand reads of a group then come from 15 or 16 unrelated offsets
-      // instead of 31 (62 of the 64 banks wanted by one access: 32 % of the section's LDS cycles were conflicts)
-      const int c = (lane < 16) ? 2 * lane : ((lane >= 32 && lane < 48) ? 2 * (lane - 32) + 1 : 0);
       int off = -1;
-      if (c == 1) off = T0;
-      else if (c >= 2 && c < 30) {
-        int k = 2 + ((c - 2) >> 1);
+      if (lane == 1) off = T0;
+      else if (lane >= 2 && lane < 30) {
+        int k = 2 + ((lane - 2) >> 1);
         int T1 = (2 * T0 + k) / (2 * k), T1b;
         if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
         else T1b = (2 * sc[k] * T0 + k) / (2 * k);
-        off = ((c - 2) & 1) ? T1b : T1;
-      } else if (c == 30 || c == 31) {
-        off = T0 + ((c & 1) ? 1 : -1);
+        off = ((lane - 2) & 1) ? T1b : T1;
+      } else if (lane == 30 || lane == 31) {
+        off = T0 + ((lane & 1) ? 1 : -1);
         if (off < 0) off = 0;
       }
-      if (off >= 0) {
-        const int a = maxperiod - off;  // y = x_lp + a
-        dots[c] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
-      }
+      // every lane runs a chain (chain_dot16_xrow takes x from the registers of the other lanes of its row); the lanes without
+      // an offset of their own run <x, x>, all of them on the same addresses (a broadcast, not a bank conflict), and drop it
+      const int a = maxperiod - (off >= 0 ? off : 0);  // y = x_lp + a
+      const float d = chain_dot16_xrow(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N, lane);
+      if (off >= 0) dots[lane] = d;
     }
     RN_WSYNC();
     float xy = dots[1];
@@ -943,9 +985,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     float xc0 = dots[30], xc2 = dots[31];
     if (cand) {  // (wave-uniform) a shorter period won: its two neighbours, T >= minperiod = 30 so both offsets are valid
       RN_WSYNC();
-      if (lane < 2) {
-        const int a = maxperiod - (T + (lane ? 1 : -1));
-        dots[32 + lane] = chain_dot8_y2(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N);
+      {
+        const int a = maxperiod - (lane < 2 ? T + (lane ? 1 : -1) : 0);
+        const float d = chain_dot16_xrow(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N, lane);
+        if (lane < 2) dots[32 + lane] = d;
       }
       RN_WSYNC();
       xc0 = dots[32];
@@ -1125,7 +1168,12 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
 // (pipelined bench, M frames/s, 1 vs K1_SPW streams per workgroup): 2048 streams 13.9 / 14.0, 4096: 20.0 / 18.3,
 // 8192: 17.7 / 19.6, 16,384: 19.0 / 22.1.  (Round 1's 80-VGPR "lean" build no longer pays at any size and is gone.)
 extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
-rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
+rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnRows rows) {
+  if (rows.n > 0) {  // a launch group of the one-frame API: the block's row at that row's own frame phase
+    const uint32_t re = rows.e[blockIdx.x];
+    analysis_body<false, 1>(g, tb, (int)((re >> 8) & 7u), (int)((re >> 12) & 3u), RnTrainArgs{}, (int)(re & 255u));
+    return;
+  }
   analysis_body<false, 1>(g, tb, slot, parity, RnTrainArgs{});
 }
 
@@ -1155,15 +1203,18 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 // samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev) {
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
   // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
   // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
   // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
-  const int parity = parity_arg & 255;
-  const bool out_s16 = parity_arg & 256;
+  const bool listed = rows.n > 0;  // a launch group of the one-frame API (rn_dev.h: RnRows)
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  const int parity = listed ? (int)((re >> 12) & 3u) : (parity_arg & 255);
+  const int prev = listed ? (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS : prev_arg;
+  const bool out_s16 = !listed && (parity_arg & 256);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
-  const int s = blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
+  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
@@ -1287,7 +1338,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   }
   regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));
   // window + overlap-add (src/denoise.c:400-407), straight from the registers
-  float *o = out + (size_t)s * RN_FRAME_SIZE;
+  float *o = listed ? rows.io + (size_t)s * RN_ROW_IO + RN_FRAME_SIZE + 4 : out + (size_t)s * RN_FRAME_SIZE;
 #pragma unroll
   for (int b = 0; b < 15; b++) {
     const int p = WAVE * b + pos;
@@ -1321,7 +1372,7 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
   const int n = g->n_streams;
   const bool single = spw_force == 1 || (spw_force == 0 && n < RN_K1_MULTI_MIN_STREAMS);
   if (single) {
-    RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1, st, e0, e1, *g, *tb, slot, parity);
+    RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1, st, e0, e1, *g, *tb, slot, parity, RnRows{});
   } else {
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
     static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
@@ -1343,6 +1394,15 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, void *out, int out_s16, int cur, int prev,
                                           hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, static_cast<float *>(out),
-            cur | (out_s16 ? 256 : 0), prev);
+            cur | (out_s16 ? 256 : 0), prev, RnRows{});
+  return hipGetLastError();
+}
+// K1 / K3 of a launch group of the one-frame API (rn_dev.h: RnRows): one one-wave workgroup per listed row
+extern "C" hipError_t rn_launch_analysis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
+  hipLaunchKernelGGL(rn_analysis_single_kernel, dim3(rows->n), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, 0, 0, *rows);
+  return hipGetLastError();
+}
+extern "C" hipError_t rn_launch_synthesis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
+  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(rows->n), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, static_cast<float *>(nullptr), 0, 0, *rows);
   return hipGetLastError();
 }

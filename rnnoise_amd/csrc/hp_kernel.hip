@@ -197,16 +197,20 @@ struct HpOneLds {
 };
 
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int in_s16) {
+rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
   __shared__ __attribute__((aligned(16))) HpOneLds L;
-  const int s = blockIdx.x, lane = threadIdx.x;
+  // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
+  const bool listed = rows.n > 0;
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, slot = listed ? (int)((re >> 8) & 7u) : slot_arg, lane = threadIdx.x;
+  const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO : in + (size_t)s * RN_FRAME_SIZE;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
   float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
   const int ring0 = RN_RING0(slot);
   {  // frame -> xin (120 float4), old part of pitch_buf -> pb (312 float4; ring0 and the ring size are multiples of 32)
-    const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
+    const float4 *x = reinterpret_cast<const float4 *>(in_row);
     const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
     float4 f[2], o[5];
 #pragma unroll
@@ -360,7 +364,7 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int in_s1
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
   static const int one_max = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : RN_HP_ONE_MAX; }();  // (A/B runs)
   if (g->n_streams <= one_max) {
-    RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16);
+    RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16, RnRows{});
     return hipGetLastError();
   }
   RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot,
@@ -369,5 +373,10 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
 }
 extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
   hipLaunchKernelGGL(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, *g, in, slot, 0);
+  return hipGetLastError();
+}
+// K0 of a launch group of the one-frame API (rn_dev.h: RnRows): one wave per listed row, float frames from the pool's pinned blocks
+extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *g, const RnRows *rows, hipStream_t st) {
+  hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), 0, 0, *rows);
   return hipGetLastError();
 }

@@ -4,6 +4,7 @@
 // x86 s8 x u8 accumulator exactly), float layers as one FMA chain per output in the
 // reference's AVX2 order.  Follows oracle/rn_oracle.c (lin_float / lin_int8 / gru_step).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "rn_dev.h"
 
@@ -300,11 +301,14 @@ __device__ __forceinline__ int one_pair_i(int v) { return __builtin_amdgcn_updat
 __device__ __forceinline__ float one_pair_f(float v) { return __int_as_float(one_pair_i(__float_as_int(v))); }
 
 extern "C" __global__ void __launch_bounds__(ONE_THREADS)
-rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
+rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
   extern __shared__ __attribute__((aligned(16))) char one_smem[];
   OneLds &O = *reinterpret_cast<OneLds *>(one_smem);
   NnLds &L = O.n;
-  const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // (rows: a launch group of the one-frame API, rn_dev.h -- the block's pool row, its VAD goes to the row's pinned frame block)
+  const bool listed = rows.n > 0;
+  const int s = listed ? (int)(rows.e[blockIdx.x] & 255u) : (int)blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float *vad_dst = listed ? rows.io + (size_t)s * RN_ROW_IO + 2 * RN_FRAME_SIZE + 4 : g.vad + s;
   const bool chain_wave = t >= ONE_ROW_THREADS;  // waves 12 (dense_out) and 13 (vad_dense)
   const bool vad_wave = wave == 13;
   const int ct = lane & 31;                      // wave 12: dense_out output of this lane (the upper half repeats the lower)
@@ -314,7 +318,7 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   const uint16_t *lut = O.lut;  // the rcpps table in LDS: three dependent lookups per unit and layer must not be L2 trips
   if (g.silence[s]) {  // src/denoise.c:474
     if (t < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + t] = 0;
-    if (t == 0) g.vad[s] = 0;
+    if (t == 0) *vad_dst = 0;
     return;
   }
   float *c1s = g.conv1_state + (size_t)s * 130;
@@ -516,18 +520,39 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     chain_segment(3);
     if (!vad_wave && lane < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + ct] = sigmoid_x86(cacc + m.dense_out.bias[ct], lut);
-    else if (vad_wave && lane == 0) g.vad[s] = sigmoid_x86(cacc + m.vad_dense.bias[0], lut);
+    else if (vad_wave && lane == 0) *vad_dst = sigmoid_x86(cacc + m.vad_dense.bias[0], lut);
   }
   ONE_TAP();  // 6: last chain segment + outputs
 #undef ONE_TAP
 }
 
+// the 125 KB of dynamic LDS are an opt-in per DEVICE (a process may hold pools and batches on several GPUs): once per device,
+// on the device the launch goes to
+static hipError_t nn_one_opt_in() {
+  static std::atomic<int> opted[64];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !opted[dev].load(std::memory_order_acquire)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(OneLds));
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) opted[dev].store(1, std::memory_order_release);
+  }
+  return hipSuccess;
+}
 extern "C" hipError_t rn_launch_nn_one(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e0,
                                        hipEvent_t e1) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_one_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(OneLds));
+  const hipError_t attr = nn_one_opt_in();
   if (attr != hipSuccess) return attr;
-  RN_LAUNCH(rn_nn_one_kernel, dim3(g->n_streams), dim3(ONE_THREADS), sizeof(OneLds), st, e0, e1, *g, *m, *tb);
+  RN_LAUNCH(rn_nn_one_kernel, dim3(g->n_streams), dim3(ONE_THREADS), sizeof(OneLds), st, e0, e1, *g, *m, *tb, RnRows{});
+  return hipGetLastError();
+}
+// K2 of a launch group of the one-frame API (rn_dev.h: RnRows): one workgroup per listed row
+extern "C" hipError_t rn_launch_nn_rows(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
+  const hipError_t attr = nn_one_opt_in();
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(rn_nn_one_kernel, dim3(rows->n), dim3(ONE_THREADS), sizeof(OneLds), st, *g, *m, *tb, *rows);
   return hipGetLastError();
 }
 

@@ -122,6 +122,21 @@ struct RnGroupDev {
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };
 
+// Row list of the one-frame API (shim: the combiner behind rnnoise_process_frame).  Concurrent rnnoise_process_frame calls on
+// states of one pool are gathered into ONE launch group: block b of the latency kernels (rn_hp_one_kernel,
+// rn_analysis_single_kernel, rn_nn_one_kernel, rn_synthesis_kernel) then works on pool row e[b] & 255 at that row's own
+// frame phase -- ring slot (e[b] >> 8) & 7, spectra slot (e[b] >> 12) & 3 -- and exchanges the frame through the row's block
+// of the pool's pinned host memory: io + row * RN_ROW_IO = in[480] | pad[4] | out[480] | vad | pad[3].  n == 0: no list --
+// block b is stream b of the group and the launch's own arguments apply (every batched call).  Passed by value: the list
+// rides in the kernel arguments, so a group costs no copy and no extra memory round trip.
+#define RN_ROWS_MAX 64
+#define RN_ROW_IO 968
+struct RnRows {
+  float *io;
+  int n;
+  uint32_t e[RN_ROWS_MAX];
+};
+
 // per-step arguments of the training-feature extraction kernel (src/dump_features.c:466-491)
 struct RnTrainArgs {
   const float *clean;      // [N][480] clean target frames (already filtered/scaled by the caller's mixer)

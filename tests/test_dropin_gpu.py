@@ -24,9 +24,12 @@ def model(blob_default):
     return capi.Model(blob_default)
 
 
-def test_pooled_states_on_four_threads(model, blob_default):
-    """70 rnnoise_create()d states (more than one 64-row pool), driven from 4 threads at once: every stream gets the
-    oracle's bits -- states are independent, and no global lock serialises them into one another's data"""
+@pytest.mark.parametrize("n_threads", [4, 32])
+def test_pooled_states_on_four_threads(model, blob_default, n_threads):
+    """70 rnnoise_create()d states (more than one 64-row pool), driven from 4 and from 32 threads at once: every stream gets the
+    oracle's bits -- states are independent, no global lock serialises them into one another's data, and the combiner that
+    gathers concurrent calls into shared launches (dropin.cpp) keeps every row at its own frame phase: state s starts s % 4
+    frames late, so the rows of one launch group sit at different ring and spectra slots"""
     T, n = 12, 70
     pcm = [synth.stream_pcm(s % 9, T, lead_silence=s % 3).astype(np.float32).reshape(T, 480) for s in range(n)]
     want = {}
@@ -40,14 +43,16 @@ def test_pooled_states_on_four_threads(model, blob_default):
 
     def work(tid):
         try:
-            for t in range(T):
-                for s in range(tid, n, 4):
-                    y, v = states[s].process_frame(pcm[s][t])
-                    got_out[s][t], got_vad[s][t] = y, v
+            for t in range(T + 3):
+                for s in range(tid, n, n_threads):
+                    f = t - s % 4
+                    if 0 <= f < T:
+                        y, v = states[s].process_frame(pcm[s][f])
+                        got_out[s][f], got_vad[s][f] = y, v
         except Exception as e:  # noqa: BLE001
             errs.append(e)
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
