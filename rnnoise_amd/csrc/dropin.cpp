@@ -22,7 +22,7 @@ StatePool *pool_new(RNNModel *model, int device) {
   }
   DeviceGuard guard(device);
   if (!guard.ok ||
-      hipHostMalloc((void **)&p->h_io, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void **)&p->h_io, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
       hipMalloc((void **)&p->d_flat, (size_t)StatePool::POOL_SLOTS * StatePool::FLAT_BLK * sizeof(float)) != hipSuccess) {
     if (p->h_io) hipHostFree(p->h_io);
     rnnoise_batch_destroy(p->batch);
@@ -121,6 +121,7 @@ int pool_step(StatePool *p, int slot, int parity, int ring_slot, long frame_no, 
 // One thread alone takes the first branch at once, every time: its latency is the four kernels', as before.
 // ---------------------------------------------------------------------------------------------
 enum : int { REQ_IDLE = 0, REQ_QUEUED, REQ_INFLIGHT, REQ_SYNCER, REQ_DONE_OK, REQ_DONE_FAIL };
+inline int req_word(uint32_t seq, int state) { return (int)(seq << 4) | state; }
 
 uint64_t now_ns() {
   timespec ts;
@@ -156,17 +157,32 @@ int effective_cpus() {
         fclose(f2);
       }
     }
-    if (quota > 0 && period > 0) cpus = std::min<long>(cpus, std::max<long>(1, (quota + period - 1) / period));
+    if (quota > 0 && period > 0) cpus = (int)std::min<long>(cpus, std::max<long>(1, (quota + period - 1) / period));
     return std::max(1, cpus);
   }();
   return n;
 }
 long futex(int *addr, int op, int val) { return syscall(SYS_futex, addr, op, val, nullptr, nullptr, 0); }
+inline volatile uint32_t *done_word(PooledRef *m) { return reinterpret_cast<volatile uint32_t *>(m->h_io + RN_ROW_IO - 1); }
 
-// publish a request's new state; wake its owner if it went to sleep on the word
-void req_set(PooledRef *m, int state) {
-  __atomic_store_n(&m->req, state, __ATOMIC_SEQ_CST);
-  if (__atomic_load_n(&m->sleeping, __ATOMIC_SEQ_CST)) futex(&m->req, FUTEX_WAKE_PRIVATE, 1);
+// Retire the entries of a group (combiner lock held): an entry's request goes INFLIGHT / SYNCER -> `state` unless its
+// caller has already seen its frame come out and left (it may be back with a new request under a new sequence number:
+// the compare-and-swap then fails and the new request is left alone).  Returns the callers asleep on their word: they are
+// woken after the lock is dropped, by address only.
+void comb_retire(const std::vector<CombMember> &grp, int state, PooledRef *self, std::vector<int *> &wake) {
+  for (const CombMember &e : grp) {
+    if (e.ref == self) continue;
+    for (int from : {REQ_INFLIGHT, REQ_SYNCER}) {
+      int expect = req_word(e.seq, from);
+      if (__atomic_compare_exchange_n(&e.ref->req, &expect, req_word(e.seq, state), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&e.ref->sleeping, __ATOMIC_SEQ_CST)) wake.push_back(&e.ref->req);
+        break;
+      }
+    }
+  }
+}
+void comb_wake(const std::vector<int *> &wake) {
+  for (int *w : wake) futex(w, FUTEX_WAKE_PRIVATE, 1);
 }
 
 int comb_free_stream(StatePool *p) {  // (lock held) a stream without a group in flight, created on demand; -1: none
@@ -184,14 +200,28 @@ int comb_free_stream(StatePool *p) {  // (lock held) a stream without a group in
   return -1;
 }
 
+// (lock held) everything queued becomes the group in flight on stream k
+void comb_take_queue(Combiner &c, int k, std::vector<CombMember> &grp) {
+  grp.swap(c.queue);
+  c.queue.clear();
+  c.busy[k] = true;
+  c.members[k] = grp;
+  for (const CombMember &e : grp) {
+    e.ref->grp = k;
+    __atomic_store_n(&e.ref->req, req_word(e.seq, REQ_INFLIGHT), __ATOMIC_SEQ_CST);  // (a queued request's caller is waiting on it)
+  }
+}
+
 // the four kernels of one frame step over the rows of `grp`, on stream k of the pool's combiner
-int comb_launch(StatePool *p, int k, const std::vector<PooledRef *> &grp) {
+int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   RNNoiseBatch *b = p->batch;
   RnRows rows;
   rows.io = p->h_io;  // (pinned host memory is mapped into the device's address space at the same address)
   rows.n = (int)grp.size();
-  for (int i = 0; i < rows.n; i++)
-    rows.e[i] = (uint32_t)grp[i]->slot | ((uint32_t)grp[i]->ring_slot << 8) | ((uint32_t)grp[i]->parity << 12);
+  for (int i = 0; i < rows.n; i++) {
+    const PooledRef *m = grp[i].ref;
+    rows.e[i] = (uint32_t)m->slot | ((uint32_t)m->ring_slot << 8) | ((uint32_t)m->parity << 12) | (grp[i].seq << 16);
+  }
   for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
   hipStream_t st = p->comb.stream[k];
   HIP_OK(rn_launch_hp_rows(&b->g, &rows, st));
@@ -201,45 +231,77 @@ int comb_launch(StatePool *p, int k, const std::vector<PooledRef *> &grp) {
   return 0;
 }
 
-// The caller `self` owns the wait for the group on stream k (it launched it, or was named its syncer): wait, hand the stream
-// to whatever queued up meanwhile, publish the results.  Returns self's own result.
-bool comb_complete(StatePool *p, int k, PooledRef *self) {
+// a launch failed part of the way: nothing of the group may outlive its frames; every member fails
+void comb_abort(StatePool *p, int k, const std::vector<CombMember> &grp, PooledRef *self) {
   Combiner &c = p->comb;
-  const bool ok = hipStreamSynchronize(c.stream[k]) == hipSuccess;
-  if (!ok) (void)hipGetLastError();
-  std::vector<PooledRef *> done, next;
+  (void)hipStreamSynchronize(c.stream[k]);
+  (void)hipGetLastError();
+  std::vector<int *> wake;
   {
     std::lock_guard<std::mutex> lk(c.mu);
-    done.swap(c.members[k]);
-    if (!c.queue.empty() && !c.gathering) {
-      next.swap(c.queue);
-      for (PooledRef *m : next) {
-        m->grp = k;
-        __atomic_store_n(&m->req, REQ_INFLIGHT, __ATOMIC_SEQ_CST);
-      }
-      c.members[k] = next;
-    } else {
-      c.busy[k] = false;
-    }
-    c.pending_returns.store((int)done.size(), std::memory_order_relaxed);
-    c.t_complete_ns.store(now_ns(), std::memory_order_relaxed);
+    c.members[k].clear();
+    c.busy[k] = false;
+    comb_retire(grp, REQ_DONE_FAIL, self, wake);
   }
-  for (PooledRef *m : done)
-    if (m != self) req_set(m, ok ? REQ_DONE_OK : REQ_DONE_FAIL);
-  if (!next.empty()) {
-    if (comb_launch(p, k, next) == 0) {
-      req_set(next[0], REQ_SYNCER);  // one of its own members waits for it
-    } else {
-      {
-        std::lock_guard<std::mutex> lk(c.mu);
-        c.members[k].clear();
-        c.busy[k] = false;
-      }
-      (void)hipStreamSynchronize(c.stream[k]);  // whatever part of the group was launched must not outlive its frames
-      for (PooledRef *m : next) req_set(m, REQ_DONE_FAIL);
+  comb_wake(wake);
+}
+
+// The caller `self` owns the wait for the group on stream k (it launched it, or was named its syncer): wait, hand the stream
+// to whatever queued up meanwhile, retire the group.  Returns self's own result.
+bool comb_complete(StatePool *p, int k, PooledRef *self) {
+  Combiner &c = p->comb;
+  // The group is complete when the last kernel has stored every member's sequence number into the member's `done` word
+  // (pinned, coherent host memory): polling that is microseconds faster than waking up from hipStreamSynchronize, and each
+  // member sees its own word without waiting for this thread.  $RNNOISE_AMD_COMBINE_POLL=0, or no word after 2 ms: the
+  // stream is synchronised instead (which is also where a GPU fault would surface).
+  static const bool poll = env_int("RNNOISE_AMD_COMBINE_POLL", 1) != 0;
+  bool self_ok = true;
+  for (bool first = true;; first = false) {
+    std::vector<CombMember> done, next;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      done = c.members[k];
     }
+    bool flagged = poll;
+    if (poll) {
+      const uint64_t give_up = now_ns() + 2000000ull;
+      for (const CombMember &e : done)
+        // (a member that has left and come back has cleared its word for its next request: the old frame is out)
+        for (unsigned it = 0; flagged && *done_word(e.ref) != e.seq && (__atomic_load_n(&e.ref->req, __ATOMIC_SEQ_CST) >> 4) == (int)e.seq; it++) {
+          cpu_relax();
+          if ((it & 255) == 255 && now_ns() > give_up) flagged = false;
+        }
+    }
+    bool ok = true;
+    if (!flagged) {
+      ok = hipStreamSynchronize(c.stream[k]) == hipSuccess;
+      if (!ok) (void)hipGetLastError();
+    }
+    if (first) self_ok = ok;
+    std::vector<int *> wake;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      c.members[k].clear();
+      if (!c.queue.empty() && !c.gathering) comb_take_queue(c, k, next);
+      else c.busy[k] = false;
+      comb_retire(done, ok ? REQ_DONE_OK : REQ_DONE_FAIL, first ? self : nullptr, wake);
+    }
+    comb_wake(wake);
+    if (next.empty()) return self_ok;
+    if (comb_launch(p, k, next)) {
+      comb_abort(p, k, next, nullptr);
+      return self_ok;
+    }
+    // one of the new group's own members waits for it: the first one that is still waiting for its frame
+    for (const CombMember &e : next) {
+      int expect = req_word(e.seq, REQ_INFLIGHT);
+      if (__atomic_compare_exchange_n(&e.ref->req, &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&e.ref->sleeping, __ATOMIC_SEQ_CST)) futex(&e.ref->req, FUTEX_WAKE_PRIVATE, 1);
+        return self_ok;
+      }
+    }
+    // (every member has already taken its frame and gone: this thread retires that group as well)
   }
-  return ok;
 }
 
 // one frame of a pooled state through the combiner: r->h_io holds the input; true when out / vad are in place
@@ -252,65 +314,85 @@ bool comb_submit(StatePool *p, PooledRef *r) {
     explicit Active(std::atomic<int> &a_) : a(a_) { a.fetch_add(1, std::memory_order_relaxed); }
     ~Active() { a.fetch_sub(1, std::memory_order_relaxed); }
   } active(c.active);
+  r->seq = (uint32_t)(r->frame_no & 0x7fff) + 1u;
+  *done_word(r) = 0;
+  const uint32_t seq = r->seq;
+  // every way out with a frame: this caller is now "on its way back" (see the gather window below)
+  auto leave = [&](bool ok) {
+    if (ok) {
+      c.t_complete_ns.store(now_ns(), std::memory_order_relaxed);
+      c.pending_returns.fetch_add(1, std::memory_order_relaxed);
+    }
+    return ok;
+  };
   int lead = -1;
-  std::vector<PooledRef *> grp;
+  std::vector<CombMember> grp;
   {
     std::unique_lock<std::mutex> lk(c.mu);
-    if (c.pending_returns.load(std::memory_order_relaxed) > 0) c.pending_returns.fetch_sub(1, std::memory_order_relaxed);
-    __atomic_store_n(&r->req, REQ_QUEUED, __ATOMIC_SEQ_CST);
-    c.queue.push_back(r);
+    if (now_ns() - c.t_complete_ns.load(std::memory_order_relaxed) > gather_ns + 5000) c.pending_returns.store(0, std::memory_order_relaxed);  // stale
+    else if (c.pending_returns.load(std::memory_order_relaxed) > 0) c.pending_returns.fetch_sub(1, std::memory_order_relaxed);
+    __atomic_store_n(&r->req, req_word(seq, REQ_QUEUED), __ATOMIC_SEQ_CST);
+    c.queue.push_back(CombMember{r, seq});
     int k = c.gathering ? -1 : comb_free_stream(p);
     if (k >= 0 && c.pending_returns.load(std::memory_order_relaxed) > 0 && gather_ns) {
-      // the other threads of the group that has just completed are on their way back: hold the stream for them
+      // the other callers that have just got their frames are on their way back: hold the stream for them
       c.gathering = true;
       lk.unlock();
       while (c.pending_returns.load(std::memory_order_relaxed) > 0 && now_ns() - c.t_complete_ns.load(std::memory_order_relaxed) < gather_ns)
         cpu_relax();
       lk.lock();
       c.gathering = false;
-      c.pending_returns.store(0, std::memory_order_relaxed);
       k = comb_free_stream(p);
     }
-    if (k >= 0 && __atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == REQ_QUEUED) {  // lead: the whole queue is this group
-      grp.swap(c.queue);
-      c.busy[k] = true;
-      c.members[k] = grp;
-      for (PooledRef *m : grp) {
-        m->grp = k;
-        __atomic_store_n(&m->req, REQ_INFLIGHT, __ATOMIC_SEQ_CST);
-      }
+    if (k >= 0 && __atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) {  // lead: the whole queue is this group
+      comb_take_queue(c, k, grp);
       lead = k;
     }
   }
   if (lead >= 0) {
     if (comb_launch(p, lead, grp)) {
-      {
-        std::lock_guard<std::mutex> lk(c.mu);
-        c.members[lead].clear();
-        c.busy[lead] = false;
-      }
-      (void)hipStreamSynchronize(c.stream[lead]);  // whatever part of the group was launched must not outlive its frames
-      for (PooledRef *m : grp)
-        if (m != r) req_set(m, REQ_DONE_FAIL);
+      comb_abort(p, lead, grp, r);
       return false;
     }
-    return comb_complete(p, lead, r);
+    return leave(comb_complete(p, lead, r));
   }
-  // wait for the request's state word: done (by the group's owner), or this thread is named the owner of its group's wait
+  // wait: for the frame (the row's `done` word, or the group's owner saying so), or to be named the owner of the group's wait
   const bool may_spin = c.active.load(std::memory_order_relaxed) <= effective_cpus();
   const uint64_t spin_until = now_ns() + (uint64_t)(may_spin ? spin_us : 20) * 1000ull;
   for (unsigned it = 0;; it++) {
-    const int s = __atomic_load_n(&r->req, __ATOMIC_SEQ_CST);
-    if (s == REQ_DONE_OK) return true;
+    const int w = __atomic_load_n(&r->req, __ATOMIC_SEQ_CST), s = w & 15;
+    if (s == REQ_SYNCER) return leave(comb_complete(p, r->grp, r));
+    if (s == REQ_DONE_OK) return leave(true);
     if (s == REQ_DONE_FAIL) return false;
-    if (s == REQ_SYNCER) return comb_complete(p, r->grp, r);
+    if (s == REQ_INFLIGHT && *done_word(r) == seq) {
+      // the frame is out: say so (nobody may name this request its group's syncer any more) and go
+      int expect = w;
+      if (__atomic_compare_exchange_n(&r->req, &expect, req_word(seq, REQ_DONE_OK), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return leave(true);
+      continue;  // (named syncer, or retired, in between: look again)
+    }
     if ((it & 63) != 63 || now_ns() < spin_until) {
       cpu_relax();
       continue;
     }
     __atomic_store_n(&r->sleeping, 1, __ATOMIC_SEQ_CST);
-    if (__atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == s) futex(&r->req, FUTEX_WAIT_PRIVATE, s);
+    if (__atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == w) futex(&r->req, FUTEX_WAIT_PRIVATE, w);
     __atomic_store_n(&r->sleeping, 0, __ATOMIC_SEQ_CST);
+  }
+}
+
+// a state that is being destroyed must not be listed in a group any more (its caller may have seen the frame come out before
+// the group's owner retired the entry)
+void comb_forget(StatePool *p, PooledRef *r) {
+  Combiner &c = p->comb;
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      bool listed = false;
+      for (int k = 0; k < c.n_streams; k++)
+        for (const CombMember &e : c.members[k]) listed |= e.ref == r;
+      if (!listed) return;
+    }
+    sched_yield();
   }
 }
 
@@ -393,6 +475,7 @@ extern "C" void rnnoise_destroy(DenoiseState *st) {
   if (!st) return;
   if (st->magic == kPooledMagic) {
     PooledRef &r = st->ref;
+    comb_forget(r.pool, &r);
     if (r.stream) {
       DeviceGuard guard(r.pool->batch->device);
       hipStreamSynchronize(r.stream);

@@ -580,6 +580,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // the waves (and so over the SIMDs: a workgroup's waves sit on different SIMDs) instead of making wave 0 the straggler of
   // every workgroup, and the two running-energy sweeps of phase 3 advance side by side.  Clear: everything on wave 0 (round 3).
   const bool spread = SPW > 1 && (slot_arg & 512);
+  const bool xrow = !(slot_arg & 1024);  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -783,15 +784,55 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   RN_WSYNC();
   for (int i = lane; i < 294; i += WAVE) xc[i] = 0;
-  // operands of the running energies of the fine search and of remove_doubling (y4 and the coarse energies are dead)
-  energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
+  if (spread) {
+    // x_lp shifted by one sample over the (not yet written) squares: the fine-search chains of phase 2 then fetch their y
+    // operand 8 bytes at a time whatever the parity of their lag, as the doubling dots do
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      const int i0 = lane + WAVE * k, i = i0 < 863 ? i0 : 862;
+      scr[SCR_XS + i] = xlp[i + 1];  // (lanes past the end rewrite element 862 with its own value)
+    }
+  } else {
+    // operands of the running energies of the fine search and of remove_doubling (y4 and the coarse energies are dead)
+    energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
+  }
   if (lane == 0) {
     mail[MAIL_BP0] = __int_as_float(bp0);
     mail[MAIL_BP1] = __int_as_float(bp1);
   }
   K1_STOP(8);
   WG_SYNC();
-  if (wave == nw2) {
+  if (spread) {
+    // narrow phase 2, spread.  Wave nw2: one ROW of 16 lanes per stream -- lanes 0..9 of the row the fine lags, lane 10 xx =
+    // <x, x> of remove_doubling, the rest idle along on <x, x> -- so that the chains of a row share x and take it from the
+    // row's registers (chain_dot16_xrow), and every y operand is an aligned 8-byte read from x_lp or its shifted copy: a
+    // third of the LDS cycles of the 12-lanes-per-stream form below, whose 4-byte reads at 24 unrelated offsets per access
+    // group were mostly bank conflicts.  Wave nw3a, at the same time on another SIMD: the start energy 1 + sum x_lp[j]^2
+    // of the fine find_best_pitch of every stream, one lane each -- the value its own sweep of phase 3 starts from.
+    if (wave == nw2) {
+      __builtin_amdgcn_s_setprio(3);
+      const int gq = lane >> 4, r = lane & 15;  // (SPW == 4 rows)
+      float *ag = arenas[gq < SPW ? gq : 0].a;
+      const int b0 = __float_as_int(ag[SCR_MAIL + MAIL_BP0]), b1 = __float_as_int(ag[SCR_MAIL + MAIL_BP1]);
+      const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
+      const bool lag = r < 10 && c >= 0 && c < 294;
+      const int a = lag ? c : 384;
+      const float sum = chain_dot16_xrow(to_lds(ag + SCR_XLP + 384), to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), 480, lane);
+      if (lag) ag[SCR_XC + c] = (-1 > sum) ? -1 : sum;
+      if (r == 10) ag[SCR_MAIL + MAIL_XX] = sum;
+      __builtin_amdgcn_s_setprio(1);
+    } else if (wave == nw3a) {
+      __builtin_amdgcn_s_setprio(3);
+      if (lane < SPW) {
+        float *ag = arenas[lane].a;
+        ag[SCR_MAIL + MAIL_SYY0F] = chain_dot8(to_lds(ag + SCR_XLP), to_lds(ag + SCR_XLP), 480, 1.f);
+      }
+      __builtin_amdgcn_s_setprio(1);
+    }
+    // every wave: the operands of the two running-energy sweeps of its own stream, over the shifted copy (dead now)
+    __syncthreads();
+    energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
+  } else if (wave == 0) {
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
     // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
     // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch
@@ -815,7 +856,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     RN_WSYNC();
     CLK_TAP(6);  // fine xcorr (+ the two start energies) of the whole workgroup (wave 0's view)
-    if (spread) __builtin_amdgcn_s_setprio(1);
   }
   if (spread) {
     // narrow phase 3, spread: the fine running energy of every stream on one wave, yy_lookup of every stream on another
@@ -929,7 +969,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       // every lane runs a chain (chain_dot16_xrow takes x from the registers of the other lanes of its row); the lanes without
       // an offset of their own run <x, x>, all of them on the same addresses (a broadcast, not a bank conflict), and drop it
       const int a = maxperiod - (off >= 0 ? off : 0);  // y = x_lp + a
-      const float d = chain_dot16_xrow(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N, lane);
+      ldsf ya = to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a));
+      const float d = xrow ? chain_dot16_xrow(to_lds(x), ya, N, lane) : (off >= 0 ? chain_dot8_y2(to_lds(x), ya, N) : 0.f);
       if (off >= 0) dots[lane] = d;
     }
     RN_WSYNC();
@@ -1358,6 +1399,13 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
       sm[RN_FRAME_SIZE - p] = v;
     }
   }
+  if (listed) {
+    // completion word of the row's request (the last word of its pinned block): the caller waiting for this frame polls it
+    // instead of waiting for the whole stream to drain.  System-scope release: the frame and the VAD are visible before it.
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(rows.io + (size_t)s * RN_ROW_IO + RN_ROW_IO - 1), re >> 16,
+                                      __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // host-visible launch helpers -----------------------------------------------------------------
@@ -1379,7 +1427,8 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
     // narrow phases spread over the waves of a workgroup (analysis_body); RNNOISE_AMD_K1_SPREAD=0: all on wave 0 (A/B runs)
     static const int spread = [] { const char *e = getenv("RNNOISE_AMD_K1_SPREAD"); return (e && atoi(e) == 0) ? 0 : 512; }();
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread, parity);
+    static const int noxrow = [] { const char *e = getenv("RNNOISE_AMD_K1_XROW"); return (e && atoi(e) == 0) ? 1024 : 0; }();
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread | noxrow, parity);
   }
   return hipGetLastError();
 }

@@ -12,6 +12,7 @@
 // once the next layer's input and this layer's recurrent operand of the next frame -- leaves the same way.
 // Arithmetic per element is the fused kernel's, so the bits are too (tests/test_gpu_parity.py runs both; tools/ab_layers.py).
 #include "nn_common.h"
+#include <stdlib.h>
 
 #define GM 4  // 16-stream tiles per workgroup
 #ifndef GW
@@ -94,18 +95,21 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 // four SIMDs re-reading B per MFMA are LDS-bound at half the MFMA rate.)
 // The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
 // boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
-#define AD 2
+// (AD is a template parameter of the kernel: rn_launch_nn_gru_layer picks the instance, $RNNOISE_AMD_GRU_AD for A/B runs)
+template <int AD>
 struct AFrags {
   v4i f[AD + 1][3];
 };
-__device__ __forceinline__ void a_fetch(AFrags &A, int step, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr, unsigned a0) {
+template <int AD>
+__device__ __forceinline__ void a_fetch(AFrags<AD> &A, int step, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr, unsigned a0) {
   const int8_t *a = step < KT ? wi : wr;
   const int kt = step < KT ? step : step - KT;
 #pragma unroll
   for (int gate = 0; gate < 3; gate++) A.f[step % (AD + 1)][gate] = ldg<v4i>(a, a0 + (unsigned)((gate * 24 * KT + kt) * 1024));
 }
 // k-steps [s0, s0 + KT) of the rolling sequence: acc[gate][t] += A(step)[gate] . image[t]
-__device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags &A, int s0, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr,
+template <int AD>
+__device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags<AD> &A, int s0, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr,
                                            unsigned a0, int lane, const int8_t (*bq)[KT * 64 * 16]) {
   asm volatile("" : "+v"(lane));  // (the images do not change inside the kernel: keep the compiler from hoisting all 48 B fragments)
 #pragma unroll
@@ -125,7 +129,8 @@ __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags &A, int s0, co
   }
 }
 
-extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+template <int AD>
+__device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
@@ -201,7 +206,7 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
       for (int t = 0; t < GM; t++) acc[gate][t] = rs;
     }
     const unsigned a0 = (unsigned)(u * KT * 64 + lane) * 16u;  // byte offset of this lane's first A fragment
-    AFrags A;
+    AFrags<AD> A;
 #pragma unroll
     for (int step = 0; step < AD; step++) a_fetch(A, step, wi.wmf, wr.wmf, a0);
     int8_gates(acc, A, 0, wi.wmf, wr.wmf, a0, lane, L.xq);
@@ -267,21 +272,32 @@ extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupD
     dbg[2] = (float)(clk3 - clk2);
   }
 }
+extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_ad3_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<3>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_ad4_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<4>(g, m, tb, layer);
+}
 
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
                                              hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
   // more than 64 KB of LDS is an opt-in, per device (a process may hold batches on several GPUs)
   static bool opted[64] = {};
+  static const int ad = [] { const char *e = getenv("RNNOISE_AMD_GRU_AD"); const int v = e ? atoi(e) : 2; return (v == 3 || v == 4) ? v : 2; }();
+  auto kernel = ad == 3 ? rn_nn_gru_ad3_kernel : (ad == 4 ? rn_nn_gru_ad4_kernel : rn_nn_gru_kernel);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!opted[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(rn_nn_gru_kernel),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
     if (attr != hipSuccess) return attr;
     opted[dev] = true;
   }
-  RN_LAUNCH(rn_nn_gru_kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer);
+  RN_LAUNCH(kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer);
   return hipGetLastError();
 }
 

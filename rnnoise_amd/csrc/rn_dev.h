@@ -126,7 +126,8 @@ struct RnGroupDev {
 // states of one pool are gathered into ONE launch group: block b of the latency kernels (rn_hp_one_kernel,
 // rn_analysis_single_kernel, rn_nn_one_kernel, rn_synthesis_kernel) then works on pool row e[b] & 255 at that row's own
 // frame phase -- ring slot (e[b] >> 8) & 7, spectra slot (e[b] >> 12) & 3 -- and exchanges the frame through the row's block
-// of the pool's pinned host memory: io + row * RN_ROW_IO = in[480] | pad[4] | out[480] | vad | pad[3].  n == 0: no list --
+// of the pool's pinned host memory: io + row * RN_ROW_IO = in[480] | pad[4] | out[480] | vad | pad[2] | done, where the last
+// kernel of the group stores the request's sequence number e[b] >> 16 into `done` once frame and VAD are out.  n == 0: no list --
 // block b is stream b of the group and the launch's own arguments apply (every batched call).  Passed by value: the list
 // rides in the kernel arguments, so a group costs no copy and no extra memory round trip.
 #define RN_ROWS_MAX 64

@@ -197,19 +197,23 @@ struct RNNoiseBatch {
 struct PooledRef;
 // The combiner of a pool (dropin.cpp): concurrent rnnoise_process_frame calls on states of one pool are gathered into launch
 // groups -- ONE set of the four latency kernels over a row list (rn_dev.h: RnRows) per group, a few groups in flight on streams
-// of their own.  Every request is queued; whoever finds a free stream takes the whole queue as a group, launches it, waits for
-// it and hands the results out; callers that find no free stream wait for their request's state word to change.
+// of their own.
+struct CombMember {
+  PooledRef *ref;
+  uint32_t seq;  // the request of `ref` this entry stands for (a state that has its frame may be back with the next one
+                 // before the group's owner has retired the old entry)
+};
 struct Combiner {
   static constexpr int MAXG = 4;
   std::mutex mu;
-  int n_streams = 0;                       // streams created so far (at most max_streams, $RNNOISE_AMD_COMBINE_STREAMS)
+  int n_streams = 0;                       // streams created so far (at most $RNNOISE_AMD_COMBINE_STREAMS)
   hipStream_t stream[MAXG] = {};
   bool busy[MAXG] = {};                    // a group is in flight on the stream
-  std::vector<PooledRef *> members[MAXG];  // ... these requests
-  std::vector<PooledRef *> queue;          // submitted, not launched yet
-  bool gathering = false;                  // a caller holds a free stream back for the threads of a group that has just completed
-  std::atomic<int> pending_returns{0};     // ... how many of them have not come back yet
-  std::atomic<uint64_t> t_complete_ns{0};  // ... and when that group completed
+  std::vector<CombMember> members[MAXG];   // ... these requests
+  std::vector<CombMember> queue;           // submitted, not launched yet
+  bool gathering = false;                  // a caller holds a free stream back for the callers that have just got their frames
+  std::atomic<int> pending_returns{0};     // callers that have just got their frame and have not come back with the next one yet
+  std::atomic<uint64_t> t_complete_ns{0};  // ... when the last of them left
   std::atomic<int> active{0};              // threads inside rnnoise_process_frame on this pool right now (spin or sleep?)
 };
 
@@ -238,9 +242,10 @@ struct PooledRef {
   float *h_io;        // the row's block of the pool's pinned frame memory
   std::mutex *mu;     // one frame at a time per state (the reference's states are not re-entrant either)
   hipStream_t stream; // only when the combiner is switched off ($RNNOISE_AMD_COMBINE=0): the state's own stream
-  int req;            // combiner: state word of the request in flight (atomic access; futex word)
+  int req;            // combiner: (sequence number << 4 | state) of the request in flight (atomic access; futex word)
   int sleeping;       // combiner: the owner sleeps on `req` (atomic access)
   int grp;            // combiner: stream slot of the group the request went into
+  uint32_t seq;       // combiner: sequence number of the request (never 0); the last kernel stores it into the row's `done` word
 };
 
 struct DenoiseState {
