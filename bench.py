@@ -67,8 +67,13 @@ ALG_BYTES = {
 }
 KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "network": "rn_nn_mfma_kernel",
              "synthesis": "rn_synthesis_kernel"}
-# shim.cpp nn_layers_min_streams(): from here up the network runs as five launches (the library honours the same variable)
+# batch.cpp nn_layers_min_streams() / nn_one_max_streams(), hp_kernel.hip RN_HP_ONE_MAX, dsp_kernels.hip RN_K1_MULTI_MIN_STREAMS:
+# the batch sizes at which the library switches kernels (it honours the same environment variables)
 NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "16384"))
+NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
+HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "3072"))
+K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))
+K1_MULTI_MIN_STREAMS = 6144
 N_CU = 256
 NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
 
@@ -79,17 +84,24 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
     three of the five and the longest."""
     if kind == "network":
         if nn != "mfma":
-            return "rn_nn_one_kernel" if n_streams <= 512 else "rn_nn_vector_kernel"  # shim.cpp: nn_one_max_streams()
+            return "rn_nn_one_kernel" if n_streams <= NN_ONE_MAX_STREAMS else "rn_nn_vector_kernel"
         return "rn_nn_gru_kernel" if n_streams >= NN_LAYERS_MIN_STREAMS else "rn_nn_mfma_kernel"
-    if kind == "analysis" and n_streams < 6144:
-        return "rn_analysis_single_kernel"  # one stream per workgroup below RN_K1_MULTI_MIN_STREAMS (dsp_kernels.hip)
-    if kind == "highpass" and n_streams <= 3072:
-        return "rn_hp_one_kernel"           # one wave per stream up to RN_HP_ONE_MAX (hp_kernel.hip)
+    if kind == "analysis" and k1_single(n_streams):
+        return "rn_analysis_single_kernel"  # one stream per workgroup
+    if kind == "highpass" and n_streams <= HP_ONE_MAX_STREAMS:
+        return "rn_hp_one_kernel"           # one wave per stream
     return KERNEL_OF[kind]
 
 
-def waves_per_launch(kind: str, n_streams: int) -> int:
-    return {"highpass": n_streams if n_streams <= 3072 else -(-n_streams // 64), "analysis": -(-n_streams // 4) * 4 if n_streams >= 6144 else n_streams,
+def k1_single(n_streams: int) -> bool:
+    return K1_SPW_FORCE == 1 or (K1_SPW_FORCE == 0 and n_streams < K1_MULTI_MIN_STREAMS)
+
+
+def waves_per_launch(kind: str, n_streams: int, nn: str = "mfma") -> int:
+    if kind == "network" and nn != "mfma":
+        return n_streams * (14 if n_streams <= NN_ONE_MAX_STREAMS else 6)  # rn_nn_one_kernel: 14 waves per stream; vector: 384 threads
+    return {"highpass": n_streams if n_streams <= HP_ONE_MAX_STREAMS else -(-n_streams // 64),
+            "analysis": n_streams if k1_single(n_streams) else -(-n_streams // 4) * 4,
             "network": (-(-n_streams // 64) if n_streams >= NN_LAYERS_MIN_STREAMS else -(-n_streams // 16)) * 8,
             "synthesis": n_streams}[kind]
 
@@ -116,7 +128,8 @@ def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma")
     per wave (PMC, profiles/pmc_by_streams.json) x valu_cost(kernel), spread over 1024 SIMDs at 2.4 GHz.
     None when a kernel of the step has no PMC record (the vector network path)."""
     n = n_streams
-    launches = [("rn_hp_kernel", -(-n // 64)), (kernel_of("analysis", n, nn), n), ("rn_synthesis_kernel", n)]
+    launches = [(kernel_of("highpass", n, nn), waves_per_launch("highpass", n)), (kernel_of("analysis", n, nn), waves_per_launch("analysis", n)),
+                ("rn_synthesis_kernel", n)]
     if nn != "mfma":
         return None
     if n >= NN_LAYERS_MIN_STREAMS:
@@ -202,14 +215,12 @@ def usable_cpus() -> int:
 
 def cpu_baseline(blob: bytes):
     """The reference itself (oracle/_ref, kind "reference") or our restatement (kind "port") on the host cores:
-    a 1-thread leg (~5 s) and an all-usable-cores leg (~12 s); see oracle/cpu_bench.c."""
+    a 1-thread leg (~4 s) and an all-usable-cores leg (~10 s); see oracle/cpu_bench.c."""
     import numpy as np
     from rnnoise_amd import synth
     ref = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
     port = os.path.join(ROOT, "oracle", "cpu_bench_port")
-    cores = usable_cpus()
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench_port"], stdout=subprocess.DEVNULL,
-                   stderr=subprocess.DEVNULL)  # always rebuilt from the source under review (a no-op when up to date)
+    cores = usable_cpus()  # (both timers are built by __graft_entry__.build(): nothing is compiled inside the benchmark)
     with tempfile.TemporaryDirectory() as td:
         bp, pp = os.path.join(td, "m.blob"), os.path.join(td, "pcm.s16")
         open(bp, "wb").write(blob)
@@ -219,7 +230,7 @@ def cpu_baseline(blob: bytes):
                 continue
             try:
                 legs = []
-                for threads, secs in ((1, 5), (cores, 12)):
+                for threads, secs in ((1, 4), (cores, 10)):
                     r = subprocess.run([exe, bp, pp, str(threads), str(secs)], capture_output=True, text=True, timeout=120)
                     legs.append(json.loads(r.stdout.strip().splitlines()[-1]))
             except Exception:
@@ -311,6 +322,22 @@ class StubBatch:
         return dict(analysis=0.3, network=0.2, synthesis=0.1, highpass=0.05, launches=1)
 
 
+def pin_rank_cpus(local_rank: int, local_world: int, torch) -> None:
+    """One node, several ranks: each rank keeps to its own slice of the CPUs this job may use and sizes its thread pools
+    for its share of the cgroup quota, so that eight ranks importing torch and launching kernels at once do not fight over
+    (say) sixteen CPUs of quota with sixteen threads each.  A no-op for one rank."""
+    if local_world <= 1:
+        return
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per >= 1:
+            os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per])
+        torch.set_num_threads(max(1, min(per, usable_cpus() // local_world)))
+    except (AttributeError, OSError):
+        pass
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -351,17 +378,23 @@ def bench_rank(a) -> dict | None:
     stub = a.stub
     if not stub and not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
-    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    # RNNOISE_AMD_BENCH_SHARE_DEVICE=1 (tests on a one-GPU box): every rank runs its shard on device 0 and the reduction goes
+    # over gloo, since RCCL refuses two ranks on one device; the line says so ("shared_device": true) and is not a scaling number
+    share = os.environ.get("RNNOISE_AMD_BENCH_SHARE_DEVICE") == "1" and not stub
+    gpu_index = 0 if share else local_rank
+    dev = torch.device("cpu") if stub else torch.device("cuda", gpu_index)
     if not stub:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu_index)
+    pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub:
+        if stub or share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = torch.device("cpu") if (stub or share) else dev  # where the reduction's tensors live
 
     def sync():
         if not stub:
@@ -385,7 +418,7 @@ def bench_rank(a) -> dict | None:
         from rnnoise_amd import capi
         model = capi.Model(blob)
         W = model.weight_bytes
-        batch = capi.Batch(model, N, device=local_rank)
+        batch = capi.Batch(model, N, device=gpu_index)
         batch.set_nn_path(1 if a.nn == "mfma" else 0)
         # inputs resident in HBM; cycle through at most `cap` distinct frames if K+W is large
         cap = max(8, min(K + Wm, (3 << 30) // (N * FRAME * 4)))
@@ -447,7 +480,11 @@ def bench_rank(a) -> dict | None:
         kms_alone = batch.kernel_ms()
         batch.set_schedule(old)
     batch.enable_timing(False)
-    times = aggregate_times(times, dist, dev)  # element-wise MAX over ranks
+    times = aggregate_times(times, dist, red_dev)  # element-wise MAX over ranks
+    shards = [[mine.start, mine.stop]]
+    if dist:
+        shards = [None] * world
+        dist.all_gather_object(shards, [mine.start, mine.stop])
     frames_per_rep = float(N * K * world)
     med = statistics.median(times)
     line = None
@@ -479,7 +516,7 @@ def bench_rank(a) -> dict | None:
             "repeats": R,
             "config": {"workload": workload_name(a, N), "streams_per_gpu": N, "frames_per_step": N * world,
                        "nn_path": a.nn, "model": a.model, "outputs_sane": sane,
-                       "stream_ids_rank0": [mine.start, mine.stop]},
+                       "stream_ids_rank0": [mine.start, mine.stop], "stream_ids_by_rank": shards},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": round(dom_ms, 4),
@@ -553,6 +590,8 @@ def bench_rank(a) -> dict | None:
             pass
         if stub:
             line["stub"] = True
+        if share and world > 1:
+            line["shared_device"] = True
         if not stub and not a.no_parity:
             try:
                 line["parity"] = parity_leg(capi, torch, batch, blob, d_in_f32, min(cap, 12), a.s16)
@@ -571,8 +610,8 @@ def bench_rank(a) -> dict | None:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=25, help="repetitions of the K-step timed region (median reported)")
     ap.add_argument("--streams", type=int, default=65536, help="concurrent streams PER GPU (configs[2]: 65536)")
     ap.add_argument("--model", choices=["default", "little"], default="default")

@@ -372,6 +372,31 @@ __device__ __forceinline__ float chain_dot8(ldsf x, ldsf y, int n, float s0 = 0.
   return s;
 }
 
+// chain_dot8 with x == y (a start energy s0 + sum y[j]^2, src/pitch.c:56-61): one operand stream instead of two, y 16-byte aligned
+__device__ __forceinline__ float chain_sq8(ldsf y, int n, float s0) {
+  float s = s0;
+  v4f_ a = lds_read16(y), b = lds_read16(y + 4);
+#pragma unroll 2
+  for (int i = 0; i < n; i += 8) {
+    const int nx = (i + 8 < n) ? i + 8 : i;
+    const v4f_ an = lds_read16(y + nx), bn = lds_read16(y + nx + 4);
+    float p0 = a.x * a.x, p1 = a.y * a.y, p2 = a.z * a.z, p3 = a.w * a.w;
+    float p4 = b.x * b.x, p5 = b.y * b.y, p6 = b.z * b.z, p7 = b.w * b.w;
+    OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
+    s = s + p0;
+    s = s + p1;
+    s = s + p2;
+    s = s + p3;
+    s = s + p4;
+    s = s + p5;
+    s = s + p6;
+    s = s + p7;
+    a = an;
+    b = bn;
+  }
+  return s;
+}
+
 // chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
 // For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
 // dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
@@ -825,7 +850,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       __builtin_amdgcn_s_setprio(3);
       if (lane < SPW) {
         float *ag = arenas[lane].a;
-        ag[SCR_MAIL + MAIL_SYY0F] = chain_dot8(to_lds(ag + SCR_XLP), to_lds(ag + SCR_XLP), 480, 1.f);
+        ag[SCR_MAIL + MAIL_SYY0F] = chain_sq8(to_lds(ag + SCR_XLP), 480, 1.f);
       }
       __builtin_amdgcn_s_setprio(1);
     }

@@ -196,6 +196,14 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
 #pragma unroll 1
   for (int ui = 0; ui < 24 / GW; ui++) {
     const int u = wave + GW * ui, unit0 = 16 * u + 4 * gq;
+    // (instrumented build, layer 0, wave 0: shader-clock deltas inside a unit tile -> slots 1376 + 5 ui + {0: input gates, 1: their
+    //  conversion, 2: recurrent gates, 3: wait + rows + conversion, 4: activations and stores}; tools/k1_cycles.py --layers)
+#if RN_INSTRUMENT
+    unsigned long long tc = (dbg && layer == 0) ? __builtin_amdgcn_s_memtime() : 0;
+#define GRU_TAP(i) do { if (dbg && layer == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg[1376 - (RN_DBG_CLK2 + 7) + 5 * ui + (i)] = (float)(n_ - tc); tc = n_; } } while (0)
+#else
+#define GRU_TAP(i) do { } while (0)
+#endif
     v4i acc[3][GM];
     v4f gi[3][GM], h_old[GM];
     // (the accumulators start from 128 * rowsum(w): acc_x86 = acc_mfma + 128 rowsum, nn_mfma.hip, without an add per value)
@@ -210,6 +218,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
 #pragma unroll
     for (int step = 0; step < AD; step++) a_fetch(A, step, wi.wmf, wr.wmf, a0);
     int8_gates(acc, A, 0, wi.wmf, wr.wmf, a0, lane, L.xq);
+    GRU_TAP(0);
 #pragma unroll
     for (int gate = 0; gate < 3; gate++) {  // float(acc_x86)*scale + subias (src/nnet_arch.h:145-151)
       const unsigned row4 = (unsigned)(gate * RN_GRU + unit0) * 4u;  // byte offset of the 4 rows
@@ -223,7 +232,9 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
         acc[gate][t] = rs;
       }
     }
+    GRU_TAP(1);
     int8_gates(acc, A, KT, wi.wmf, wr.wmf, a0, lane, L.hq);
+    GRU_TAP(2);
     // all of this wave's loads have landed (the last A fragment was just used): its f32 rows for this tile are in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -247,6 +258,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     // The next tile's rows start their HBM trip here, under the ~4k cycles of activation VALU work that load nothing:
     // vmcnt retires in order, so any load issued behind them (the constants above, the next A fragments) waits them out.
     __builtin_amdgcn_sched_barrier(0);
+    GRU_TAP(3);
     if (u + GW < 24) rows_fetch(ui + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -264,6 +276,8 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
         stg<int>(himg, (unsigned)((tile0 + t) * (KT * 64 * 16) + frag_off(n, unit0)), pack4_g(hn[0], hn[1], hn[2], hn[3]));
       }
     }
+    GRU_TAP(4);
+#undef GRU_TAP
   }
   if (dbg && tile0 * TS < N) {
     const unsigned long long clk3 = __builtin_amdgcn_s_memtime();

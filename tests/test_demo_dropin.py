@@ -43,7 +43,7 @@ def test_demo_output_is_byte_identical(tmp_path):
     from oracle.binding import Oracle
     blob = load_blob("default")
     (tmp_path / "weights_blob.bin").write_bytes(blob)
-    T = 200  # 2 s (the full 10 s case is the same code path; kept short because every frame is 3 PCIe round trips)
+    T = 1000  # BASELINE configs[0]: 10 s of 48 kHz audio through the reference's own demo program
     pcm = synth.stream_pcm(12, T, lead_silence=4)
     raw = np.concatenate([pcm, np.arange(100, dtype=np.int16)])  # + a partial tail frame that must be dropped
     raw.tofile(tmp_path / "in.raw")

@@ -63,8 +63,10 @@ def _tiled_check(blob, N, calls, silent_stream):
     m.close()
 
 
-def test_65536_stream_batch_properties(blob_default):
-    """BASELINE configs[2] = the bench default: 14 frames as calls of 5 + 1 + 8"""
+@pytest.mark.parametrize("rcp_profile", ["intel", "host"], indirect=True)
+def test_65536_stream_batch_properties(blob_default, rcp_profile):
+    """BASELINE configs[2] = the bench default: 14 frames as calls of 5 + 1 + 8 -- on the profile of the committed goldens and on
+    "host", the profile a deployed process (and bench.py) runs on: the rcpps of this machine's CPU"""
     _tiled_check(blob_default, 65536, (5, 1, 8), silent_stream=21)
 
 
@@ -162,3 +164,28 @@ def test_two_processes_share_one_gpu(blob_default):
         crc = [int(x) for x in so.split("CRC")[1].split()]
         assert crc == [zlib.crc32(want["out"].tobytes()), zlib.crc32(want["gains"].tobytes()),
                        zlib.crc32(want["vad"].tobytes())], f"process starting at stream {first}"
+
+
+def test_bench_with_two_ranks_on_one_device():
+    """bench.py's own multi-rank path on real kernels where only one GPU exists: two ranks of torch.distributed.run, both on
+    device 0 (RNNOISE_AMD_BENCH_SHARE_DEVICE=1: gloo carries the reduction, RCCL refuses two ranks on one device) -- disjoint
+    stream shards, whole-job aggregate over both ranks, rank-0-only line, parity leg green.  Not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, RNNOISE_AMD_BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "4096", "--steps", "4",
+                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["shared_device"] is True and d["scaling"] == "weak"
+    assert d["config"]["streams_per_gpu"] == 4096 and d["config"]["frames_per_step"] == 8192
+    assert d["config"]["stream_ids_by_rank"] == [[0, 4096], [4096, 8192]]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / 8192 - 1) < 0.01
+    assert d["parity"]["bit_identical"] is True and d["config"]["outputs_sane"] is True
+    assert "cpu_baseline" not in d

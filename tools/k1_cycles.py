@@ -27,6 +27,10 @@ for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
             print("    layer-wise GRU kernel (wave 0 of each 64-stream workgroup): prologue issue | wait to barrier | 3 unit tiles")
             for k in range(3):
                 print(f"    gru{k+1}: {c[:, 3*k].mean():9.0f} {c[:, 3*k+1].mean():9.0f} {c[:, 3*k+2].mean():9.0f}")
+            u = d[::64, 1376:1391]
+            print("    gru1, inside a unit tile (wave 0): input gates | conversion | recurrent gates | wait + rows + conversion | activations + stores")
+            for ui in range(3):
+                print(f"    unit tile {ui}: " + " ".join(f"{u[:, 5 * ui + i].mean():9.0f}" for i in range(5)))
     clk = d[:, 1348:1360]
     print(f"--- N={n}: mean shader clocks per section over streams (total {clk.sum(1).mean():.0f}) ---")
     for k, name in enumerate(NAMES):
