@@ -120,6 +120,22 @@ def valu_cost(kernel: str) -> float:
         return 4.15
 
 
+def valu_cost_kind(kernel: str) -> str:
+    """"dynamic" when the kernel's mean cost weights its code sections by MEASURED per-section instruction counts (tools/valu_mix.py
+    --k1-sections: the analysis kernel, whose loops execute a mix that is not the file's average), "static" otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
+            return "dynamic" if str(json.load(f)["kernels"][kernel].get("weighting", "static")).startswith("dynamic") else "static"
+    except Exception:
+        return "static"
+
+
+def clock_hz(rec) -> float:
+    """Shader clock a kernel RAN at: GRBM_GUI_ACTIVE / duration of its PMC pass (profiles/pmc_by_streams.json: clock_ghz);
+    the guide's 2.4 GHz maximum when the record carries no measurement."""
+    return float(rec["clock_ghz"]) * 1e9 if rec and rec.get("clock_ghz") else CLOCK_HZ
+
+
 VALU_FLOOR = 2.26  # clocks per wave64 instruction if every one were a plain f32 VOP2 (the guide's vector-f32 peak, as measured)
 
 
@@ -136,13 +152,13 @@ def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma")
         launches += [("rn_nn_front_kernel", -(-n // 16) * 8), ("rn_nn_gru_kernel", 3 * (-(-n // 64)) * 8), ("rn_nn_dense_kernel", -(-n // 64) * 8)]
     else:
         launches += [("rn_nn_mfma_kernel", -(-n // 16) * 8)]
-    cycles = 0.0
+    cycles = 0.0  # (seconds x SIMDs: every kernel at the clock it was measured at)
     for kernel, waves in launches:
         r = pmc_record(kernel, n, model)
         if not r or "valu_per_wave" not in r:
             return None
-        cycles += waves * r["valu_per_wave"] * valu_cost(r.get("kernel", kernel))
-    return 1e3 * cycles / N_SIMD / CLOCK_HZ
+        cycles += waves * r["valu_per_wave"] * valu_cost(r.get("kernel", kernel)) / clock_hz(r)
+    return 1e3 * cycles / N_SIMD
 
 
 def load_blob(name: str = "default") -> bytes:
@@ -548,36 +564,42 @@ def bench_rank(a) -> dict | None:
                 "note": "same workload, every kernel on one stream (no overlap between kernels), outside the timed region"}
             wa = waves_per_launch(da, N)  # (of ONE launch, also for the layer-wise network)
             if "valu_per_wave" in pa:
-                ti = pa["valu_per_wave"] * wa * valu_cost(pa.get("kernel", na)) / N_SIMD / CLOCK_HZ
+                ti = pa["valu_per_wave"] * wa * valu_cost(pa.get("kernel", na)) / N_SIMD / clock_hz(pa)
                 line["roofline_standalone"]["valu_issue_frac"] = round(ti / (da_ms * 1e-3), 4)
                 line["roofline_standalone"]["valu_note"] = (f"{pa['valu_per_wave']} VALU instructions per wave (PMC) x "
                                                            f"{valu_cost(pa.get('kernel', na)):.2f} clk (instruction mix priced with profiles/r3_valu_issue.txt) "
-                                                           "over 1024 SIMDs at 2.4 GHz")
+                                                           f"over 1024 SIMDs at {clock_hz(pa) / 1e9:.2f} GHz")
+                line["roofline_standalone"]["clock_ghz"] = round(clock_hz(pa) / 1e9, 3)
             if "lds_cycles_per_wave" in pa:
-                tl = pa["lds_cycles_per_wave"] * wa / N_CU / CLOCK_HZ
+                tl = pa["lds_cycles_per_wave"] * wa / N_CU / clock_hz(pa)
                 line["roofline_standalone"]["lds_port_frac"] = round(tl / (da_ms * 1e-3), 4)
         if "valu_per_wave" in pmc and dom_ms > 0:
             # VALU-issue bound of the dominant launch: instructions per wave (PMC) x the mean issue cost of this kernel's
             # instruction mix (valu_cost) x waves, spread over 1024 SIMDs at 2.4 GHz.  frac_f32_peak prices every instruction
             # at the plain-f32 rate instead (the guide's vector peak): a floor no mix with DPP / f64 / selects can reach.
             cpi = valu_cost(pmc.get("kernel", kname))
-            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * cpi / N_SIMD / CLOCK_HZ
+            t_issue = pmc["valu_per_wave"] * waves_per_launch(dom, N) * cpi / N_SIMD / clock_hz(pmc)
             line["roofline_valu"] = {"bound": "valu-issue", "kernel": kname, "valu_insts_per_wave": pmc["valu_per_wave"],
-                                     "waves": waves_per_launch(dom, N), "clocks_per_inst": cpi, "issue_bound_ms": round(1e3 * t_issue, 4),
+                                     "waves": waves_per_launch(dom, N), "clocks_per_inst": cpi,
+                                     "clocks_per_inst_kind": valu_cost_kind(pmc.get("kernel", kname)),
+                                     "clock_ghz": round(clock_hz(pmc) / 1e9, 3),
+                                     "clock_source": "GRBM_GUI_ACTIVE / duration of the kernel's PMC pass" if pmc.get("clock_ghz") else "nominal maximum (no measurement in profiles/)",
+                                     "issue_bound_ms": round(1e3 * t_issue, 4),
                                      "frac": round(t_issue / (dom_ms * 1e-3), 4),
                                      "frac_f32_peak": round(t_issue * VALU_FLOOR / cpi / (dom_ms * 1e-3), 4),
-                                     "peak": "1024 SIMDs x 2.4 GHz / clocks_per_inst wave64 instructions/s; clocks_per_inst = this kernel's "
+                                     "peak": "1024 SIMDs x clock_ghz / clocks_per_inst wave64 instructions/s; clocks_per_inst = this kernel's "
                                              "instruction mix priced with the per-instruction costs measured in profiles/r3_valu_issue.txt "
                                              "(frac_f32_peak: every instruction at 2.26 clk, the measured plain-f32 rate)",
                                      "source": pmc.get("source", "profiles/")}
         if "lds_cycles_per_wave" in pmc and dom_ms > 0:
             # LDS-port bound: SQ_LDS_IDX_ACTIVE cycles per wave (PMC: cycles the CU's one LDS pipe is busy for this wave,
             # bank-conflict replays included) x waves / 256 CUs / 2.4 GHz
-            t_lds = pmc["lds_cycles_per_wave"] * waves_per_launch(dom, N) / N_CU / CLOCK_HZ
+            t_lds = pmc["lds_cycles_per_wave"] * waves_per_launch(dom, N) / N_CU / clock_hz(pmc)
             line["roofline_lds"] = {"bound": "lds-port", "kernel": kname, "lds_cycles_per_wave": pmc["lds_cycles_per_wave"],
                                     "waves": waves_per_launch(dom, N), "port_bound_ms": round(1e3 * t_lds, 4),
                                     "frac": round(t_lds / (dom_ms * 1e-3), 4),
-                                    "peak": "one LDS pipe per CU: 256 CUs x 2.4 GHz port-cycles/s", "source": pmc.get("source", "profiles/")}
+                                    "clock_ghz": round(clock_hz(pmc) / 1e9, 3),
+                                    "peak": "one LDS pipe per CU: 256 CUs x clock_ghz port-cycles/s", "source": pmc.get("source", "profiles/")}
         try:  # the whole step against VALU issue: every kernel of it is issue-bound to first order
             vi = step_valu_issue_ms(N, a.model, a.nn)
             if vi and med > 0:
@@ -585,7 +607,7 @@ def bench_rank(a) -> dict | None:
                                               "frac": round(vi / (1e3 * med / K), 4),
                                               "definition": "sum over the step's kernels of waves x VALU instructions per wave (PMC passes under "
                                                             "profiles/) x that kernel's mix-priced clocks per instruction (profiles/valu_mix.json, "
-                                                            "profiles/r3_valu_issue.txt), over 1024 SIMDs at 2.4 GHz, divided by ms_per_step"}
+                                                            "profiles/r3_valu_issue.txt), over 1024 SIMDs at each kernel's measured clock, divided by ms_per_step"}
         except Exception:
             pass
         if stub:

@@ -66,6 +66,34 @@ __device__ __forceinline__ float sigmoid_g(float x, const uint16_t *lut_b) {  //
   num = fmaf(num, rcp_b(den, lut_b), .5f);
   return __builtin_amdgcn_fmed3f(num, 0.f, 1.f);
 }
+// The same two activations in two halves, so that the table lookups of MANY elements are in flight together: the first half
+// ends by requesting the element's rcpps table entry from LDS, the second half uses it.  Taken one element at a time (sigmoid,
+// sigmoid, tanh, each waiting for its own lookup) the 48 activations of a unit tile spent 8-15 k cycles, most of them waiting
+// for LDS round trips one after the other (shader-clock taps, tools/k1_cycles.py --layers).  Same operations in the same
+// order per element: same bits.
+struct ActPre {
+  float numx;     // num * x
+  uint32_t b, v;  // bits of den; its table entry (rn_rcp_x86)
+};
+__device__ __forceinline__ ActPre act_pre(float x, const uint16_t *lut, float N0, float N1, float N2, float D0, float D1, float D2) {
+  const float x2 = x * x;
+  const float num = fmaf(fmaf(N2, x2, N1), x2, N0);
+  const float den = fmaf(fmaf(D2, x2, D1), x2, D0);
+  ActPre a;
+  a.numx = num * x;
+  a.b = __float_as_uint(den);
+  a.v = lut[(a.b >> 11) & 0xfff];
+  return a;
+}
+__device__ __forceinline__ float act_rcp(const ActPre &a) { return __uint_as_float((a.v << 11) + (RN_RCP_K - (a.b & 0x7f800000u))); }
+__device__ __forceinline__ ActPre sigmoid_pre(float x, const uint16_t *lut) {  // src/vec_avx.h:426-445
+  return act_pre(x, lut, 238.13200378f, 6.02452230f, 0.00950985f, 952.72399902f, 103.34200287f, 0.74287558f);
+}
+__device__ __forceinline__ float sigmoid_fin(const ActPre &a) { return __builtin_amdgcn_fmed3f(fmaf(a.numx, act_rcp(a), .5f), 0.f, 1.f); }
+__device__ __forceinline__ ActPre tanh_pre(float x, const uint16_t *lut) {  // src/vec_avx.h:398-416
+  return act_pre(x, lut, 952.52801514f, 96.39235687f, 0.60863042f, 952.72399902f, 413.36801147f, 11.88600922f);
+}
+__device__ __forceinline__ float tanh_fin(const ActPre &a) { return __builtin_amdgcn_fmed3f(a.numx * act_rcp(a), -1.f, 1.f); }
 __device__ __forceinline__ int pack4_g(float a, float b, float c, float d) {  // src/vec_avx.h:326-341, then -128 per byte
   unsigned p = 0;
   p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a, 127.f, 127.f)), 0, p);
@@ -130,7 +158,9 @@ __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags<AD> &A, int s0
 }
 
 template <int AD>
-__device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer) {
+__device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer_arg) {
+  const int layer = layer_arg & 3;
+  const bool batched_act = !(layer_arg & 4);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
@@ -261,15 +291,36 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     GRU_TAP(3);
     if (u + GW < 24) rows_fetch(ui + 1);
     __builtin_amdgcn_sched_barrier(0);
+    // one tile's 4 rows at a time: eight sigmoid lookups in flight, then four tanh lookups ($RNNOISE_AMD_GRU_ACT=0 at launch:
+    // element by element, as before -- A/B runs)
 #pragma unroll
     for (int t = 0; t < GM; t++) {
       v4f hn;
+      if (batched_act) {
+        ActPre az[4], ar[4], ah[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float z = sigmoid_g(gi[0][t][r] + gr[0][t][r], lut);
-        const float rg = sigmoid_g(gi[1][t][r] + gr[1][t][r], lut);
-        const float hh = tanh_g(gi[2][t][r] + gr[2][t][r] * rg, lut);
-        hn[r] = z * h_old[t][r] + (1 - z) * hh;
+        for (int r = 0; r < 4; r++) {
+          az[r] = sigmoid_pre(gi[0][t][r] + gr[0][t][r], lut);
+          ar[r] = sigmoid_pre(gi[1][t][r] + gr[1][t][r], lut);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float z[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          z[r] = sigmoid_fin(az[r]);
+          ah[r] = tanh_pre(gi[2][t][r] + gr[2][t][r] * sigmoid_fin(ar[r]), lut);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) hn[r] = z[r] * h_old[t][r] + (1 - z[r]) * tanh_fin(ah[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float z = sigmoid_g(gi[0][t][r] + gr[0][t][r], lut);
+          const float rg = sigmoid_g(gi[1][t][r] + gr[1][t][r], lut);
+          const float hh = tanh_g(gi[2][t][r] + gr[2][t][r] * rg, lut);
+          hn[r] = z * h_old[t][r] + (1 - z) * hh;
+        }
       }
       if (live[t]) {  // (live implies tile0 + t < n_tiles)
         stg<v4f>(st, (unsigned)(sn[t] * RN_GRU + unit0) * 4u, hn);
@@ -311,7 +362,8 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
     if (attr != hipSuccess) return attr;
     opted[dev] = true;
   }
-  RN_LAUNCH(kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer);
+  static const int act_flag = [] { const char *e = getenv("RNNOISE_AMD_GRU_ACT"); return (e && atoi(e) == 0) ? 4 : 0; }();
+  RN_LAUNCH(kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer | act_flag);
   return hipGetLastError();
 }
 

@@ -25,14 +25,22 @@ timeout 600 "$R/rnnoise_amd/csrc/build/valu_issue" > "$O/valu_issue.txt" 2>&1
 RNNOISE_AMD_NN_LAYERS_MIN=100000000 python "$R/tools/ab_layers.py" 65536 2>&1 | grep -E "^N=|^n=" > "$O/network_schedules_65536.txt"
 python "$R/tools/k1_cycles.py" 65536 --nn --layers 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
 python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"
+# the drop-in call from plain C threads (the combiner of dropin.cpp), and the same with a stream per state as in round 3
+( cd "$R" && gcc -O2 -Iinclude tools/configs0_mt.c -o /tmp/configs0_mt -Lrnnoise_amd -l:librnnoise_amd.so -Wl,-rpath,$R/rnnoise_amd -lpthread )
+python -c "import lzma;open('/tmp/default.blob','wb').write(lzma.decompress(open('$R/tests/golden/default.blob.xz','rb').read()))"
+: > "$O/configs0_cthreads.txt"
+for t in 1 2 4 8 16 32 64; do timeout 120 /tmp/configs0_mt /tmp/default.blob $t 3000 2>&1 | sed "s/^/combined launches:   /" >> "$O/configs0_cthreads.txt"; done
+for t in 1 4 16 64; do RNNOISE_AMD_COMBINE=0 timeout 200 /tmp/configs0_mt /tmp/default.blob $t 2000 2>&1 | sed "s/^/a stream per state:  /" >> "$O/configs0_cthreads.txt"; done
 python "$R/tools/fft_bench.py" 2>&1 | grep -v amdgpu.ids > "$O/fft_bench.txt"
 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline --repeats 5 > "$O/trace.log" 2>&1
 python "$R/tools/prof_summary.py" "$(ls "$O"/trace/*/*_results.db | head -1)" \
   "python bench.py --no-cpu-baseline --repeats 5  [configs[2]: 65536 streams, MFMA network path, 3-stream pipeline + one stand-alone pass]" > "$O/kernel_stats.txt"
-G="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES,SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT,TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum,FETCH_SIZE,WRITE_SIZE"
+G="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES,SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES,SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT,TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum,FETCH_SIZE,WRITE_SIZE,GRBM_GUI_ACTIVE"
 # PMC passes on the one-stream schedule (RNNOISE_AMD_PIPE=9): a kernel's counters are then its own, not a neighbour's
 RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_65536" "$G" -- python "$R/bench.py" --no-cpu-baseline --steps 4 --warmup 1 --repeats 2 > "$O/pmc_65536.csv" 2>&1
 RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_4096" "$G" -- python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 8 --warmup 2 --repeats 2 > "$O/pmc_4096.csv" 2>&1
 RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_little_32768" "$G" -- python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 --steps 4 --warmup 1 --repeats 2 > "$O/pmc_little_32768.csv" 2>&1
-rm -rf "$O"/pmc_65536 "$O"/pmc_4096 "$O"/pmc_little_32768 "$O"/trace "$O"/b.log
+bash "$R/tools/k1_prefix.sh" prof/k1_prefix 65536 > /dev/null 2>&1
+cp "$O/k1_prefix/k1_prefix.txt" "$O/k1_sections.txt"; cp "$O/k1_prefix/k1_prefix.csv" "$O/k1_sections.csv"
+rm -rf "$O"/pmc_65536 "$O"/pmc_4096 "$O"/pmc_little_32768 "$O"/trace "$O"/b.log "$O"/k1_prefix
 ls -la "$O"

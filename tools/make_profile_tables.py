@@ -17,7 +17,11 @@ for n in ("bench_65536", "bench_4096", "bench_4096_vector", "bench_16384", "benc
           "bench_hostio_s16_65536", "bench_s16_65536", "bench_4096_fpc1", "bench_16384_fpc1"):
     if os.path.exists(os.path.join(src, n + ".json")) and os.path.getsize(os.path.join(src, n + ".json")) > 10:
         shutil.copy(os.path.join(src, n + ".json"), os.path.join(dst, f"{pre}_{n}.json"))
-for n in ("serial_times", "section_taps_65536", "configs0", "fft_bench", "network_schedules_65536", "pcie_peak", "valu_issue"):
+for n in ("k1_sections.csv",):
+    if os.path.exists(os.path.join(src, n)):
+        shutil.copy(os.path.join(src, n), os.path.join(dst, f"{pre}_{n}"))
+for n in ("serial_times", "section_taps_65536", "configs0", "configs0_cthreads", "k1_sections", "fft_bench", "network_schedules_65536", "pcie_peak",
+          "valu_issue"):
     if os.path.exists(os.path.join(src, n + ".txt")):
         shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
@@ -46,10 +50,10 @@ for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warm
     hdr = (f"# PMC counters, mean per kernel launch: RNNOISE_AMD_PIPE=9 rocprofv3 --kernel-trace --pmc <group> -- python bench.py --no-cpu-baseline {cmd}\n"
            "# (MFMA path, every kernel on one stream so that a kernel's counters are its own); one run per counter group (tools/pmc_collect.py);\n"
            "# SQ_* are summed over all shader engines, *_CYCLES in quad-cycles; cyc/VALU = 4*SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU;\n"
-           "# LDS%/CU = SQ_LDS_IDX_ACTIVE / 256 CUs / (kernel duration x 2.1 GHz); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is in KiB\n"
+           "# clock = GRBM_GUI_ACTIVE / XCDs / duration of the same pass (GHz); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is in KiB\n"
            "# and on gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section)\n")
     t = (f"{'kernel':<26}{'waves':>8}{'VALU/wave':>10}{'SALU/wave':>10}{'LDS/wave':>9}{'MFMA/wave':>10}{'VMEM/wave':>10}{'cyc/VALU':>9}"
-         f"{'valu_act%':>10}{'wait%':>7}{'LDScyc/wave':>12}{'conflict%':>10}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}\n")
+         f"{'valu_act%':>10}{'wait%':>7}{'LDScyc/wave':>12}{'conflict%':>10}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}{'clock_GHz':>10}\n")
     for r in rows:
         def g(k):
             return float(r[k]) if r.get(k) else 0.0
@@ -61,8 +65,21 @@ for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warm
               f"{100 * g('SQ_ACTIVE_INST_VALU') / (g('SQ_WAVE_CYCLES') or 1):>10.1f}{100 * g('SQ_WAIT_ANY') / (g('SQ_WAVE_CYCLES') or 1):>7.1f}"
               f"{g('SQ_LDS_IDX_ACTIVE') / w:>12.0f}{100 * g('SQ_LDS_BANK_CONFLICT') / (g('SQ_LDS_IDX_ACTIVE') or 1):>10.1f}"
               f"{100 * g('TCC_HIT_sum') / ((g('TCC_HIT_sum') + g('TCC_MISS_sum')) or 1):>8.1f}"
-              f"{g('FETCH_SIZE'):>11.0f}{g('WRITE_SIZE'):>11.0f}{hbm:>12.0f}\n")
+              f"{g('FETCH_SIZE'):>11.0f}{g('WRITE_SIZE'):>11.0f}{hbm:>12.0f}")
+        cl = next((g("GRBM_GUI_ACTIVE") / dv / g("GRBM_PASS_DURATION_NS") for dv in (1, 8)
+                   if g("GRBM_PASS_DURATION_NS") and 0.5 <= g("GRBM_GUI_ACTIVE") / dv / g("GRBM_PASS_DURATION_NS") <= 3.0), 0.0)
+        t += f"{cl:>10.3f}\n" if cl else f"{'':>10}\n"
+        # shader clock of the kernel: GRBM_GUI_ACTIVE (busy cycles, summed over the XCDs rocprofv3 reports) / its duration in
+        # the same pass; the divisor (1 or 8 XCDs) is the one that lands in a shader clock's range
+        clock = None
+        if g("GRBM_GUI_ACTIVE") and g("GRBM_PASS_DURATION_NS"):
+            for div in (1, 8):
+                c = g("GRBM_GUI_ACTIVE") / div / g("GRBM_PASS_DURATION_NS")
+                if 0.5 <= c <= 3.0:
+                    clock = round(c, 3)
+                    break
         by[model].setdefault(str(n_streams), {})[r["kernel"].replace("_single", "")] = {
+            **({"clock_ghz": clock} if clock else {}),
             "hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"), "write_kib_per_launch": g("WRITE_SIZE"),
             "valu_per_wave": round(g("SQ_INSTS_VALU") / w), "valu_cycles_per_inst": round(cpi, 2),
             "lds_cycles_per_wave": round(g("SQ_LDS_IDX_ACTIVE") / w), "kernel": r["kernel"], "source": f"profiles/{pre}_pmc_{tag}.txt"}

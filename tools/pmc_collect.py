@@ -28,6 +28,14 @@ for gi, g in enumerate(groups):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            # duration of the same dispatch (this pass): GRBM_GUI_ACTIVE / duration = the shader clock the kernel ran at
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                acc[row["Kernel_Name"]]["GRBM_PASS_DURATION_NS"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    if "GRBM_GUI_ACTIVE" in g and not any("GRBM_PASS_DURATION_NS" in v for v in acc.values()):
+        # older csv layout: durations from the kernel trace of the same pass, matched by dispatch order per kernel
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                acc[row["Kernel_Name"]]["GRBM_PASS_DURATION_NS"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 names = sorted({c for k in acc.values() for c in k})
 print("kernel," + ",".join(names) + ",launches")
 for k, cs in sorted(acc.items()):

@@ -11,7 +11,10 @@ This tool classifies every VALU instruction in the gfx950 code object of the giv
 kernel, the static instruction mix and its mean cost.  The kernels' hot parts are straight-line (fully unrolled chains), so
 the static mix is taken as the dynamic one: bound_cycles_per_wave = SQ_INSTS_VALU per wave (PMC) x mean cost.
 
-usage: tools/valu_mix.py [--json profiles/valu_mix.json] rnnoise_amd/csrc/build/*.o
+usage: tools/valu_mix.py [--json profiles/valu_mix.json] [--k1-sections rnnoise_amd/csrc/build_instr/dsp_kernels.o k1_prefix.csv]
+                         rnnoise_amd/csrc/build/*.o
+  --k1-sections: rn_analysis_kernel's mean cost becomes a DYNAMIC one -- its sections priced separately and weighted by the
+  per-section instruction counts of the PMC passes (the kernel's loops execute a mix that is not the file's average)
 """
 import json
 import os
@@ -68,11 +71,60 @@ def kernels_of(obj):
     return out
 
 
+def k1_dynamic(instr_obj, csv_path):
+    """Mean issue cost of rn_analysis_kernel weighted by what actually EXECUTES: the instrumented build's code is cut at its
+    K1_STOP checks (s_cmp_eq_u32 <reg>, k -- the same boundaries tools/k1_prefix.sh measures between), every section's static
+    mix is priced, and the sections are summed with the per-wave VALU counts the PMC passes MEASURED for them (k1_prefix.csv)
+    as weights -- a section whose loops run 30 times counts 30 times, with the mix of its own code, not the file's average."""
+    import csv
+    ins = kernels_of(instr_obj).get("rn_analysis_kernel")
+    if not ins:
+        return None
+    rows = list(csv.DictReader(open(csv_path)))
+    cum = {int(r["stop"]): float(r["valu_per_wave"]) for r in rows}
+    whole = cum.pop(0)
+    stops = sorted(cum)
+    dyn = [cum[k] - (cum[k - 1] if k > 1 else 0.0) for k in stops] + [whole - cum[stops[-1]]]
+    # section boundaries: first `s_cmp_eq_u32 sN, k` for k = 1, 2, ... in program order
+    cuts, want = [], 1
+    for i, (mn, ops) in enumerate(ins):
+        if mn == "s_cmp_eq_u32" and re.match(rf"\s*s\d+,\s*{want}\s*$", ops):
+            cuts.append(i)
+            want += 1
+    if len(cuts) != len(stops):
+        return None
+    bounds = [0] + cuts + [len(ins)]
+    tot_clk = tot_valu = 0.0
+    per_section = []
+    for si in range(len(bounds) - 1):
+        sec = ins[bounds[si]:bounds[si + 1]]
+        base = bounds[si]
+        # loop membership by backward branches (objdump prints targets as <kernel+0xOFF>; fall back: no loops)
+        inloop = [False] * len(sec)
+        n = {"fast": 0.0, "std": 0.0, "trans": 0.0}
+        nl = {"fast": 0.0, "std": 0.0, "trans": 0.0}
+        for j, (mn, ops) in enumerate(sec):
+            if mn.startswith("v_") and not mn.startswith(("v_mfma", "v_smfmac")):
+                (nl if inloop[j] else n)[classify(mn, ops)] += 1
+        stat = sum(n.values())
+        d = max(dyn[si], 0.0)
+        scale = d / stat if stat else 0.0  # (without loop information: the whole section scaled to its measured count)
+        clk = sum(n[c] * COST[c] for c in n) * scale
+        per_section.append((d, clk / d if d else 0.0))
+        tot_clk += clk
+        tot_valu += d
+    return {"mean_cycles": round(tot_clk / tot_valu, 3) if tot_valu else None, "valu_dynamic_per_wave": round(tot_valu),
+            "sections": [{"valu": round(d), "mean_cycles": round(c, 3)} for d, c in per_section]}
+
+
 def main():
     args = sys.argv[1:]
     jpath = None
+    k1 = None
     if args and args[0] == "--json":
         jpath, args = args[1], args[2:]
+    if args and args[0] == "--k1-sections":  # --k1-sections <instrumented dsp_kernels.o> <k1_prefix.csv>
+        k1, args = (args[1], args[2]), args[3:]
     res = {}
     for obj in args:
         for k, ins in kernels_of(obj).items():
@@ -98,6 +150,18 @@ def main():
             mean = sum(n[c] * COST[c] for c in n) / tot
             res[k] = {"valu_static": tot, "fast": n["fast"], "std": n["std"], "trans": n["trans"], "mfma_static": mfma,
                       "select_on_vcc": sel_vcc, "fast_by_analogy": unmeasured_fast, "mean_cycles": round(mean, 3)}
+    for r in res.values():
+        r["weighting"] = "static"
+    if k1 and "rn_analysis_kernel" in res:
+        d = k1_dynamic(*k1)
+        if d and d["mean_cycles"]:
+            r = res["rn_analysis_kernel"]
+            r["mean_cycles_static"] = r["mean_cycles"]
+            r["mean_cycles"] = d["mean_cycles"]
+            r["weighting"] = ("dynamic: the instrumented build's sections (K1_STOP boundaries) priced one by one and weighted by the VALU "
+                              "instructions per wave the PMC passes measured for each (tools/k1_prefix.sh)")
+            r["valu_dynamic_per_wave"] = d["valu_dynamic_per_wave"]
+            r["sections"] = d["sections"]
     print(f"# mean VALU issue cost per kernel from the static instruction mix; classes: fast {COST['fast']} clk (plain f32/u32 VOP2, no SGPR "
           f"source), std {COST['std']} clk, trans {COST['trans']} clk  [profiles/r3_valu_issue.txt, >= 2 waves per SIMD]")
     print(f"{'kernel':<30}{'VALU':>7}{'fast':>7}{'std':>7}{'trans':>7}{'MFMA':>7}{'sel(vcc)':>9}{'mean clk':>10}")
