@@ -175,31 +175,32 @@ class Model:
     """RNNModel from a "DNNw" weight blob (reference: rnnoise_model_from_buffer, rnnoise.h:102)."""
 
     def __init__(self, blob: bytes):
+        self._L = lib()  # the library image that owns this handle (capi.instrumented() swaps the global one)
         self._blob = bytes(blob)  # borrowed by the library for the model's lifetime
-        self.h = lib().rnnoise_model_from_buffer(self._blob, len(self._blob))
+        self.h = self._L.rnnoise_model_from_buffer(self._blob, len(self._blob))
         if not self.h:
             raise ValueError("rnnoise_model_from_buffer failed")
 
     @property
     def weight_bytes(self) -> int:
-        w = lib().rnnoise_model_weight_bytes(self.h)
+        w = self._L.rnnoise_model_weight_bytes(self.h)
         if w < 0:
             raise ValueError("weight blob rejected")
         return int(w)
 
     def pack(self) -> bytes:
         """the model as a GPU-native "RNPK" pack (rnnoise_amd_model_pack); loadable wherever a blob is"""
-        n = lib().rnnoise_amd_model_pack(self.h, None, 0)
+        n = self._L.rnnoise_amd_model_pack(self.h, None, 0)
         if n <= 0:
             raise ValueError("weight blob rejected")
         buf = C.create_string_buffer(n)
-        if lib().rnnoise_amd_model_pack(self.h, buf, n) != n:
+        if self._L.rnnoise_amd_model_pack(self.h, buf, n) != n:
             raise RuntimeError("rnnoise_amd_model_pack failed")
         return buf.raw
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rnnoise_model_free(self.h)
+            self._L.rnnoise_model_free(self.h)
             self.h = None
 
     def __del__(self):
@@ -213,15 +214,16 @@ class Batch:
     """N concurrent streams on one GPU (include/rnnoise_amd.h)."""
 
     def __init__(self, model: Model, n_streams: int, device: int = 0):
+        self._L = lib()  # the library image that owns this handle (capi.instrumented() swaps the global one)
         self.model = model
         self.n = n_streams
-        self.h = lib().rnnoise_batch_create(model.h, n_streams, device)
+        self.h = self._L.rnnoise_batch_create(model.h, n_streams, device)
         if not self.h:
             raise RuntimeError("rnnoise_batch_create failed (no GPU / bad model / out of memory)")
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rnnoise_batch_destroy(self.h)
+            self._L.rnnoise_batch_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -231,17 +233,17 @@ class Batch:
             pass
 
     def reset(self):
-        if lib().rnnoise_batch_reset(self.h):
+        if self._L.rnnoise_batch_reset(self.h):
             raise RuntimeError("reset failed")
 
     def set_nn_path(self, path: int) -> int:
-        r = lib().rnnoise_batch_set_nn_path(self.h, path)
+        r = self._L.rnnoise_batch_set_nn_path(self.h, path)
         if r < 0:
             raise RuntimeError(f"network path {path} unsupported")
         return r
 
     def set_schedule(self, schedule: int) -> int:
-        r = lib().rnnoise_batch_set_schedule(self.h, schedule)
+        r = self._L.rnnoise_batch_set_schedule(self.h, schedule)
         if r < 0:
             raise RuntimeError(f"schedule {schedule} unsupported")
         return r
@@ -254,7 +256,7 @@ class Batch:
         out = np.empty_like(pcm)
         vad = np.empty((T, N), np.float32)
         gains = np.empty((T, N, NB_BANDS), np.float32) if want_gains else None
-        if lib().rnnoise_batch_process(self.h, _fp(out), _fp(pcm), _fp(vad), _fp(gains), T):
+        if self._L.rnnoise_batch_process(self.h, _fp(out), _fp(pcm), _fp(vad), _fp(gains), T):
             raise RuntimeError("rnnoise_batch_process failed")
         return out, vad, gains
 
@@ -268,7 +270,7 @@ class Batch:
         vad = np.empty((T, N), np.float32)
         gains = np.empty((T, N, NB_BANDS), np.float32) if want_gains else None
         sp = C.POINTER(C.c_short)
-        if lib().rnnoise_batch_process_s16(self.h, out.ctypes.data_as(sp), pcm.ctypes.data_as(sp), _fp(vad), _fp(gains), T):
+        if self._L.rnnoise_batch_process_s16(self.h, out.ctypes.data_as(sp), pcm.ctypes.data_as(sp), _fp(vad), _fp(gains), T):
             raise RuntimeError("rnnoise_batch_process_s16 failed")
         return out, vad, gains
 
@@ -277,25 +279,25 @@ class Batch:
         and written by DMA in place; pageable memory goes through the library's pinned bounce buffers."""
         fp = C.POINTER(C.c_float)
         pp = C.POINTER(C.c_short) if s16 else fp
-        fn = lib().rnnoise_batch_process_s16 if s16 else lib().rnnoise_batch_process
+        fn = self._L.rnnoise_batch_process_s16 if s16 else self._L.rnnoise_batch_process
         if fn(self.h, C.cast(out_ptr, pp), C.cast(in_ptr, pp), C.cast(vad_ptr or None, fp), C.cast(gains_ptr or None, fp), n_frames):
             raise RuntimeError("rnnoise_batch_process failed")
 
     def process_device(self, d_out: int, d_in: int, d_vad: int, d_gains: int, n_frames: int, stream: int = 0, s16: bool = False):
         """Raw device pointers (ints), asynchronous on `stream` (a hipStream_t handle); s16: the PCM buffers hold int16."""
-        fn = lib().rnnoise_batch_process_device_s16 if s16 else lib().rnnoise_batch_process_device
+        fn = self._L.rnnoise_batch_process_device_s16 if s16 else self._L.rnnoise_batch_process_device
         if fn(self.h, d_out, d_in, d_vad or None, d_gains or None, n_frames, stream or None):
             raise RuntimeError("rnnoise_batch_process_device failed")
 
     def export_state(self, stream: int) -> np.ndarray:
         s = np.empty(STATE_FLOATS, np.float32)
-        if lib().rnnoise_batch_export_state(self.h, stream, _fp(s)):
+        if self._L.rnnoise_batch_export_state(self.h, stream, _fp(s)):
             raise RuntimeError("export_state failed")
         return s
 
     def import_state(self, stream: int, state: np.ndarray):
         state = np.ascontiguousarray(state, np.float32)
-        if lib().rnnoise_batch_import_state(self.h, stream, _fp(state)):
+        if self._L.rnnoise_batch_import_state(self.h, stream, _fp(state)):
             raise RuntimeError("import_state failed")
 
     def debug_last(self):
@@ -303,7 +305,7 @@ class Batch:
         s = np.empty(self.n, np.int32)
         p = np.empty(self.n, np.int32)
         ip = C.POINTER(C.c_int)
-        if lib().rnnoise_batch_debug_last(self.h, _fp(f), s.ctypes.data_as(ip), p.ctypes.data_as(ip)):
+        if self._L.rnnoise_batch_debug_last(self.h, _fp(f), s.ctypes.data_as(ip), p.ctypes.data_as(ip)):
             raise RuntimeError("debug_last failed")
         return f, s, p
 
@@ -316,27 +318,27 @@ class Batch:
         ia = [np.ascontiguousarray(a, np.int32) for a in (lowpass, band_lp, noise_free)]
         rec = np.empty((T, N, 98), np.float32)
         ip = C.POINTER(C.c_int)
-        if lib().rnnoise_batch_train_features(self.h, _fp(rec), _fp(clean), _fp(noisy), _fp(vad),
+        if self._L.rnnoise_batch_train_features(self.h, _fp(rec), _fp(clean), _fp(noisy), _fp(vad),
                                               *[a.ctypes.data_as(ip) for a in ia], T):
             raise RuntimeError("rnnoise_batch_train_features failed")
         return rec
 
     def debug_pitch(self, arm_only: bool = False):
         if arm_only:
-            lib().rnnoise_batch_debug_pitch(self.h, None)
+            self._L.rnnoise_batch_debug_pitch(self.h, None)
             return None
         d = np.empty((self.n, 1400), np.float32)
-        if lib().rnnoise_batch_debug_pitch(self.h, _fp(d)):
+        if self._L.rnnoise_batch_debug_pitch(self.h, _fp(d)):
             raise RuntimeError("debug_pitch failed")
         return d
 
     def enable_timing(self, on: bool = True):
-        lib().rnnoise_batch_enable_timing(self.h, int(on))
+        self._L.rnnoise_batch_enable_timing(self.h, int(on))
 
     def kernel_ms(self):
         ms = (C.c_double * 4)()
         n = C.c_long(0)
-        if lib().rnnoise_batch_kernel_ms(self.h, ms, C.byref(n)):
+        if self._L.rnnoise_batch_kernel_ms(self.h, ms, C.byref(n)):
             raise RuntimeError("kernel_ms failed")
         return dict(analysis=ms[0], network=ms[1], synthesis=ms[2], highpass=ms[3], launches=n.value)
 
@@ -345,19 +347,20 @@ class DenoiseState:
     """The reference's one-stream object (rnnoise_create / process_frame / destroy)."""
 
     def __init__(self, model: Model):
+        self._L = lib()  # the library image that owns this handle (capi.instrumented() swaps the global one)
         self.model = model
-        self.h = lib().rnnoise_create(model.h)
+        self.h = self._L.rnnoise_create(model.h)
         if not self.h:
             raise RuntimeError("rnnoise_create failed")
 
     def process_frame(self, frame: np.ndarray):
         x = np.ascontiguousarray(frame, np.float32).copy()
-        vad = lib().rnnoise_process_frame(self.h, _fp(x), _fp(x))  # in place, like rnnoise_demo.c:57
+        vad = self._L.rnnoise_process_frame(self.h, _fp(x), _fp(x))  # in place, like rnnoise_demo.c:57
         return x, vad
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rnnoise_destroy(self.h)
+            self._L.rnnoise_destroy(self.h)
             self.h = None
 
     def __del__(self):

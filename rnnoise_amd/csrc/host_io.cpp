@@ -103,13 +103,17 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   float *r_vad = reinterpret_cast<float *>(r_out + RING * slot_pcm), *r_g = reinterpret_cast<float *>(reinterpret_cast<char *>(r_vad) + RING * slot_vad);
   FrameIoHooks hk;
   hk.ring = RING;
-  // Copies.  Uploads and downloads ALTERNATE ON ONE COPY STREAM (io.down), in the order the frame pipeline asks for them:
-  // each then finds the DMA engine free.  With two copies in flight the runtime executes one of them as a blit kernel (256
-  // workgroups x 512 lanes) whose PCIe-bound stores stall what runs beside it -- the analysis kernel took 2.3 ms instead of
-  // 1.1 (rocprofv3 kernel + memory-copy trace) -- and a copy stream per direction plus the pipeline's three streams is more
-  // than the four hardware queues the runtime multiplexes streams onto.  $RNNOISE_AMD_HOSTIO_COPY=hp (A/B runs): uploads on
-  // the high-pass stream instead, downloads alone on the copy stream.
-  static const bool one_copy_stream = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY"); return !e || !strcmp(e, "one"); }();
+  // Copies.  int16 frames: uploads and downloads ALTERNATE ON ONE COPY STREAM (io.down), in the order the frame pipeline asks
+  // for them: each then finds the DMA engine free.  With two copies in flight the runtime executes one of them as a blit kernel
+  // (256 workgroups x 512 lanes) whose PCIe-bound stores stall what runs beside it -- the analysis kernel took 2.3 ms instead
+  // of 1.1 (rocprofv3 kernel + memory-copy trace) -- and a copy stream per direction plus the pipeline's three streams is more
+  // than the four hardware queues the runtime multiplexes streams onto.  One direction at a time moves an int16 step's
+  // 2 x 63 MB in 2.2 ms, just above the kernels' time: 28.0 M frames/s either way (profiles/r4_hostio_modes.txt).
+  // float frames (2 x 126 MB per step) are bound by the link whatever the kernels do, and there both directions at once win:
+  // uploads ride on the high-pass stream, downloads keep the copy stream -- 19.9 M frames/s against 14.6 M.
+  // $RNNOISE_AMD_HOSTIO_COPY = one | hp forces a mode (A/B runs).
+  static const int copy_mode_env = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY"); return !e ? 0 : (!strcmp(e, "one") ? 1 : 2); }();
+  const bool one_copy_stream = copy_mode_env ? copy_mode_env == 1 : s16;
   hk.before_hp = [&](int f, hipStream_t sc) -> int {
     if (!one_copy_stream) {
       HIP_OK(hipMemcpyAsync(r_in + (size_t)(f % RING) * fsz, in + (size_t)f * fsz, fsz, hipMemcpyHostToDevice, sc));
@@ -176,7 +180,11 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   const int rc = batch_process_device_impl(b, r_out, r_in, r_vad, r_g, n_frames, io.run, s16, &hk);
   b->schedule = keep;
   if (rc) {
-    (void)hipDeviceSynchronize();  // whatever was queued must not outlive the caller's buffers
+    // whatever was queued must not outlive the caller's buffers; and some of the call's frames may have run while the batch's
+    // frame bookkeeping was not advanced: the streams are no longer in a state any caller knows -- back to the initial one
+    (void)hipDeviceSynchronize();
+    fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: a GPU step failed inside the call; the batch has been reset\n");
+    (void)rnnoise_batch_reset(b);
     return -1;
   }
   HIP_OK(hipStreamSynchronize(io.down));

@@ -349,7 +349,12 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
   d.device = device;
   ON_DEVICE(device);
   HIP_OK(hipMalloc(&d.mem, sm.st.bytes.size()));
-  HIP_OK(hipMemcpy(d.mem, sm.st.bytes.data(), sm.st.bytes.size(), hipMemcpyHostToDevice));
+  if (hipMemcpy(d.mem, sm.st.bytes.data(), sm.st.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    fprintf(stderr, "[rnnoise_amd] cannot copy the model to device %d\n", device);
+    (void)hipGetLastError();
+    hipFree(d.mem);
+    return -1;
+  }
   const uint8_t *base = static_cast<const uint8_t *>(d.mem);
   RnLinearDev *dst[10] = {&d.dev.conv1, &d.dev.conv2, &d.dev.gru_in[0], &d.dev.gru_rec[0], &d.dev.gru_in[1], &d.dev.gru_rec[1],
                           &d.dev.gru_in[2], &d.dev.gru_rec[2], &d.dev.dense_out, &d.dev.vad_dense};
@@ -390,8 +395,14 @@ int model_on_device(RNNModel *m, int device, RnModelDev &out) {
         for (int i = 0; i < nout; i++) fw4[((size_t)(j / 4) * nout + i) * 4 + (j & 3)] = fw[(size_t)j * nout + i];
       o_fw4 = rows.add(fw4.data(), 4 * fw4.size());
     }
-    HIP_OK(hipMalloc(&d.mem_rows, rows.bytes.size()));
-    HIP_OK(hipMemcpy(d.mem_rows, rows.bytes.data(), rows.bytes.size(), hipMemcpyHostToDevice));
+    if (hipMalloc(&d.mem_rows, rows.bytes.size()) != hipSuccess ||
+        hipMemcpy(d.mem_rows, rows.bytes.data(), rows.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      fprintf(stderr, "[rnnoise_amd] cannot place the model's row-major copy on device %d\n", device);
+      (void)hipGetLastError();
+      if (d.mem_rows) hipFree(d.mem_rows);
+      hipFree(d.mem);
+      return -1;
+    }
     const uint8_t *rb = static_cast<const uint8_t *>(d.mem_rows);
     for (int i = 1; i <= 7; i++) {
       dst[i]->wrow = reinterpret_cast<const int *>(rb + o_w[i]);
