@@ -94,6 +94,45 @@ __device__ __forceinline__ ActPre tanh_pre(float x, const uint16_t *lut) {  // s
   return act_pre(x, lut, 952.52801514f, 96.39235687f, 0.60863042f, 952.72399902f, 413.36801147f, 11.88600922f);
 }
 __device__ __forceinline__ float tanh_fin(const ActPre &a) { return __builtin_amdgcn_fmed3f(a.numx * act_rcp(a), -1.f, 1.f); }
+// ... and on PAIRS of elements in packed math (v_pk_mul / v_pk_fma / v_pk_add_f32: two elements per instruction).  Each wave
+// of this kernel is alone on its SIMD's VALU most of the time (its partner is in its MFMA block), and a lone wave issues one
+// instruction per ~5 cycles whatever the instruction: halving the instruction count of the polynomial halves its time.  The
+// packed forms round each component exactly like the scalar ones (an fma is an fma, a multiply a multiply).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct ActPre2 {
+  v2f numx;
+  uint32_t b0, b1, v0, v1;
+};
+__device__ __forceinline__ ActPre2 act_pre2(v2f x, const uint16_t *lut, float N0, float N1, float N2, float D0, float D1, float D2) {
+  const v2f x2 = x * x;
+  const v2f num = pk_fma(pk_fma(v2f{N2, N2}, x2, v2f{N1, N1}), x2, v2f{N0, N0});
+  const v2f den = pk_fma(pk_fma(v2f{D2, D2}, x2, v2f{D1, D1}), x2, v2f{D0, D0});
+  ActPre2 a;
+  a.numx = num * x;
+  a.b0 = __float_as_uint(den.x);
+  a.b1 = __float_as_uint(den.y);
+  a.v0 = lut[(a.b0 >> 11) & 0xfff];
+  a.v1 = lut[(a.b1 >> 11) & 0xfff];
+  return a;
+}
+__device__ __forceinline__ v2f act_rcp2(const ActPre2 &a) {
+  return v2f{__uint_as_float((a.v0 << 11) + (RN_RCP_K - (a.b0 & 0x7f800000u))), __uint_as_float((a.v1 << 11) + (RN_RCP_K - (a.b1 & 0x7f800000u)))};
+}
+__device__ __forceinline__ ActPre2 sigmoid_pre2(v2f x, const uint16_t *lut) {
+  return act_pre2(x, lut, 238.13200378f, 6.02452230f, 0.00950985f, 952.72399902f, 103.34200287f, 0.74287558f);
+}
+__device__ __forceinline__ v2f sigmoid_fin2(const ActPre2 &a) {
+  const v2f r = pk_fma(a.numx, act_rcp2(a), v2f{.5f, .5f});
+  return v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};
+}
+__device__ __forceinline__ ActPre2 tanh_pre2(v2f x, const uint16_t *lut) {
+  return act_pre2(x, lut, 952.52801514f, 96.39235687f, 0.60863042f, 952.72399902f, 413.36801147f, 11.88600922f);
+}
+__device__ __forceinline__ v2f tanh_fin2(const ActPre2 &a) {
+  const v2f r = a.numx * act_rcp2(a);
+  return v2f{__builtin_amdgcn_fmed3f(r.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(r.y, -1.f, 1.f)};
+}
 __device__ __forceinline__ int pack4_g(float a, float b, float c, float d) {  // src/vec_avx.h:326-341, then -128 per byte
   unsigned p = 0;
   p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a, 127.f, 127.f)), 0, p);
@@ -297,22 +336,30 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     for (int t = 0; t < GM; t++) {
       v4f hn;
       if (batched_act) {
-        ActPre az[4], ar[4], ah[4];
+        ActPre2 az[2], ar[2], ah[2];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          az[r] = sigmoid_pre(gi[0][t][r] + gr[0][t][r], lut);
-          ar[r] = sigmoid_pre(gi[1][t][r] + gr[1][t][r], lut);
+        for (int p = 0; p < 2; p++) {
+          const v2f gz = {gi[0][t][2 * p], gi[0][t][2 * p + 1]}, rz = {gr[0][t][2 * p], gr[0][t][2 * p + 1]};
+          const v2f gg = {gi[1][t][2 * p], gi[1][t][2 * p + 1]}, rr = {gr[1][t][2 * p], gr[1][t][2 * p + 1]};
+          az[p] = sigmoid_pre2(gz + rz, lut);
+          ar[p] = sigmoid_pre2(gg + rr, lut);
         }
         __builtin_amdgcn_sched_barrier(0);
-        float z[4];
+        v2f z[2];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          z[r] = sigmoid_fin(az[r]);
-          ah[r] = tanh_pre(gi[2][t][r] + gr[2][t][r] * sigmoid_fin(ar[r]), lut);
+        for (int p = 0; p < 2; p++) {
+          z[p] = sigmoid_fin2(az[p]);
+          const v2f gh = {gi[2][t][2 * p], gi[2][t][2 * p + 1]}, rh = {gr[2][t][2 * p], gr[2][t][2 * p + 1]};
+          ah[p] = tanh_pre2(gh + rh * sigmoid_fin2(ar[p]), lut);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) hn[r] = z[r] * h_old[t][r] + (1 - z[r]) * tanh_fin(ah[r]);
+        for (int p = 0; p < 2; p++) {
+          const v2f ho = {h_old[t][2 * p], h_old[t][2 * p + 1]};
+          const v2f hv = z[p] * ho + (v2f{1.f, 1.f} - z[p]) * tanh_fin2(ah[p]);
+          hn[2 * p] = hv.x;
+          hn[2 * p + 1] = hv.y;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
