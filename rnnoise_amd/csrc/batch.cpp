@@ -369,7 +369,7 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
         TimedLaunch t0(b, 1), t1(b, 1), t2(b, 1), t3(b, 1), t4(b, 1);
         hipEvent_t ev[5][2] = {{t0.start(), t0.stop()}, {t1.start(), t1.stop()}, {t2.start(), t2.stop()}, {t3.start(), t3.stop()},
                                {t4.start(), t4.stop()}};
-        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, side_k1 ? 1 : 0, st, ev));
+        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, ev));
       } else {
         TimedLaunch t(b, 1);
         b->img_valid = false;

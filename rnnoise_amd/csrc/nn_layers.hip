@@ -20,19 +20,14 @@
 #endif
 #define GTHREADS (64 * GW)
 
-// W: waves per GRU workgroup.  8 (two per SIMD) is the stand-alone optimum; 4 (one per SIMD, 72 KB of LDS) leaves room on the CU
-// for two analysis workgroups of the next frame, whose waves then fill the issue slots a lone GRU wave leaves empty (a wave
-// alone on a SIMD issues one VALU instruction per ~5 cycles): the pipelined schedule asks for that variant.
-template <int W>
-struct GruLdsT {
+struct GruLds {
   uint16_t lut[4096];            // rcpps table (rn_dev.h: rcp16)
   int8_t xq[GM][KT * 64 * 16];   // layer input images
   int8_t hq[GM][KT * 64 * 16];   // recurrent state images
-  float hrow[W][GM * TS][16];    // per wave: the f32 state of the 16 units of its CURRENT unit tile for the workgroup's 64 streams
-                                 // (the blend z*h + (1-z)*candidate needs them exact); the next tile's rows are fetched into
-                                 // the same buffer once this tile's have been read into registers
+  float hrow[GW][24 / GW][GM * TS][16];  // per wave and unit tile: the f32 state of its 16 units for the workgroup's 64 streams
+                                         // (the blend z*h + (1-z)*candidate needs them exact)
 };
-static_assert(sizeof(GruLdsT<8>) <= 96 * 1024 && sizeof(GruLdsT<4>) <= 80 * 1024, "GRU workgroup LDS");
+static_assert(sizeof(GruLds) <= 160 * 1024, "one workgroup per CU, all of its LDS");
 
 // Addressing in the GRU kernel is (uniform base, unsigned 32-bit BYTE offset): one VGPR per address instead of a 64-bit
 // pair per pointer (rn_launch_nn_layers refuses batches whose state plane exceeds 4 GB)
@@ -167,7 +162,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 // four SIMDs re-reading B per MFMA are LDS-bound at half the MFMA rate.)
 // The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
 // boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
-// (AD is a template parameter of the kernel: rn_launch_nn_gru_layer picks the instance, $RNNOISE_AMD_GRU_AD for A/B runs)
+// (AD is a template parameter of the kernel body; 3 and 4 k-steps ahead were measured too and change nothing: profiles/r4_gru_experiments.txt)
 template <int AD>
 struct AFrags {
   v4i f[AD + 1][3];
@@ -201,9 +196,8 @@ __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags<AD> &A, int s0
   }
 }
 
-template <int AD, int W>
+template <int AD>
 __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer_arg) {
-  typedef GruLdsT<W> GruLds;
   const int layer = layer_arg & 3;
   const bool batched_act = !(layer_arg & 4);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -233,27 +227,27 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   // Prologue: the two images of the workgroup's GM tiles and the rcpps table go straight from HBM to LDS (1 KB per wave
   // instruction, no staging registers, no ds_write pass: the images are stored in exactly the order LDS wants), then
   // this wave's f32 rows for its first unit tile.
-  auto rows_fetch = [&](int ui) {  // f32 state of units 16 u .. 16 u + 15, u = wave + W ui, of the 64 streams: 4 pieces
-    const int u = wave + W * ui;
+  auto rows_fetch = [&](int ui) {  // f32 state of units 16 u .. 16 u + 15, u = wave + GW ui, of the 64 streams: 4 pieces
+    const int u = wave + GW * ui;
 #pragma unroll
     for (int i = 0; i < GM * TS * 16 * 4 / 1024; i++) {
       const int idx = i * 64 + lane, row = idx >> 2, seg = idx & 3, s = tile0 * TS + row, sc = s < N ? s : N - 1;
-      dma_1k(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), lds_addr(&L.hrow[wave][0][0]) + i * 1024);
+      dma_1k(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), lds_addr(&L.hrow[wave][ui][0][0]) + i * 1024);
     }
   };
   {
     constexpr int NCHUNK = 2 * GM * KT;  // 1 KB pieces
 #pragma unroll
-    for (int j = 0; j < (NCHUNK + W - 1) / W; j++) {
-      const int c = wave + j * W;  // wave-uniform
+    for (int j = 0; j < (NCHUNK + GW - 1) / GW; j++) {
+      const int c = wave + j * GW;  // wave-uniform
       if (c < NCHUNK) {
         const int which = c / (GM * KT), cc = c - which * (GM * KT), t = cc / KT, kt = cc - t * KT;
         const int tile = (tile0 + t < n_tiles) ? tile0 + t : n_tiles - 1;
         dma_1k((which ? himg : xin) + ((size_t)tile * (KT * 64 * 16) + kt * 1024 + lane * 16), lds_addr(which ? L.hq[t] : L.xq[t]) + kt * 1024);
       }
     }
-    for (int c = wave; c < 8; c += W)  // the LUT is 8 pieces
-      dma_1k(reinterpret_cast<const uint32_t *>(tb.rcp16) + c * 256 + lane * 4, lds_addr(L.lut) + c * 1024);
+    static_assert(GW >= 8, "the LUT is 8 pieces");
+    if (wave < 8) dma_1k(reinterpret_cast<const uint32_t *>(tb.rcp16) + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
     rows_fetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -267,10 +261,10 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   // The two waves of a SIMD run the same phases from the same barrier: left alone they want the MFMA pipe together and
   // the VALU together.  Giving one of them issue priority lets it run ahead, after which one's MFMA block overlaps the
   // other's epilogue.
-  if (wave < W / 2) __builtin_amdgcn_s_setprio(2);
+  if (wave < GW / 2) __builtin_amdgcn_s_setprio(2);
 #pragma unroll 1
-  for (int ui = 0; ui < 24 / W; ui++) {
-    const int u = wave + W * ui, unit0 = 16 * u + 4 * gq;
+  for (int ui = 0; ui < 24 / GW; ui++) {
+    const int u = wave + GW * ui, unit0 = 16 * u + 4 * gq;
     // (instrumented build, layer 0, wave 0: shader-clock deltas inside a unit tile -> slots 1376 + 5 ui + {0: input gates, 1: their
     //  conversion, 2: recurrent gates, 3: wait + rows + conversion, 4: activations and stores}; tools/k1_cycles.py --layers)
 #if RN_INSTRUMENT
@@ -313,7 +307,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     // all of this wave's loads have landed (the last A fragment was just used): its f32 rows for this tile are in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][TS * t + n][4 * gq]);
+    for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][ui][TS * t + n][4 * gq]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     v4f gr[3][GM];
 #pragma unroll
@@ -334,7 +328,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     // vmcnt retires in order, so any load issued behind them (the constants above, the next A fragments) waits them out.
     __builtin_amdgcn_sched_barrier(0);
     GRU_TAP(3);
-    if (u + W < 24) rows_fetch(ui + 1);
+    if (u + GW < 24) rows_fetch(ui + 1);
     __builtin_amdgcn_sched_barrier(0);
     // one tile's 4 rows at a time: eight sigmoid lookups in flight, then four tanh lookups ($RNNOISE_AMD_GRU_ACT=0 at launch:
     // element by element, as before -- A/B runs)
@@ -390,35 +384,26 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     dbg[2] = (float)(clk3 - clk2);
   }
 }
-extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  gru_body<2, 8>(g, m, tb, layer);
-}
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) rn_nn_gru_w4_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  gru_body<2, 4>(g, m, tb, layer);
+extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2>(g, m, tb, layer);
 }
 
-// `pipelined`: the launch runs beside the analysis kernel of the next frame (multi-frame calls on the three-stream schedule)
-extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, int pipelined,
-                                             hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
+                                             hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
-  // more than 64 KB of LDS is an opt-in, per device and kernel (a process may hold batches on several GPUs)
-  static bool opted[2][64] = {};
-  // $RNNOISE_AMD_GRU_W = 8 | 4 forces a variant; default: 4 waves per workgroup in pipelined calls, 8 otherwise
-  static const int w_env = [] { const char *e = getenv("RNNOISE_AMD_GRU_W"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
-  const int w = w_env ? w_env : (pipelined ? 4 : 8);
+  // more than 64 KB of LDS is an opt-in, per device (a process may hold batches on several GPUs)
+  static bool opted[64] = {};
+  auto kernel = rn_nn_gru_kernel;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  const size_t lds = w == 4 ? sizeof(GruLdsT<4>) : sizeof(GruLdsT<8>);
-  if (!opted[w == 4][dev]) {
-    const hipError_t attr = hipFuncSetAttribute(w == 4 ? reinterpret_cast<const void *>(rn_nn_gru_w4_kernel) : reinterpret_cast<const void *>(rn_nn_gru_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!opted[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
     if (attr != hipSuccess) return attr;
-    opted[w == 4][dev] = true;
+    opted[dev] = true;
   }
   static const int act_flag = [] { const char *e = getenv("RNNOISE_AMD_GRU_ACT"); return (e && atoi(e) == 0) ? 4 : 0; }();
-  const dim3 grid((n_tiles + GM - 1) / GM);
-  if (w == 4) RN_LAUNCH(rn_nn_gru_w4_kernel, grid, dim3(256), lds, st, e0, e1, *g, *m, *tb, layer | act_flag);
-  else RN_LAUNCH(rn_nn_gru_kernel, grid, dim3(512), lds, st, e0, e1, *g, *m, *tb, layer | act_flag);
+  RN_LAUNCH(kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer | act_flag);
   return hipGetLastError();
 }
 

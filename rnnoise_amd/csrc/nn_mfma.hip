@@ -75,20 +75,20 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m
   RN_LAUNCH(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
-extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, int pipelined,
-                                             hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
+                                             hipEvent_t e0, hipEvent_t e1);
 extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e0,
                                          hipEvent_t e1);
 // the same network as five launches (front, three GRU layers at 64 streams per workgroup, dense); ev[i] = the optional
 // (start, stop) events of launch i: each kernel is timed on its own, the five durations add up to the network's
-extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int pipelined, hipStream_t st,
+extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                           hipEvent_t ev[5][2]) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
   if ((size_t)g->n_streams * RN_GRU * 4 >= (1ull << 32)) return hipErrorNotSupported;  // 32-bit offsets in nn_layers.hip
   const dim3 grid((g->n_streams + TS - 1) / TS);
   RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
   for (int k = 0; k < 3; k++) {
-    hipError_t e = rn_launch_nn_gru_layer(g, m, tb, k, pipelined, st, ev[1 + k][0], ev[1 + k][1]);
+    hipError_t e = rn_launch_nn_gru_layer(g, m, tb, k, st, ev[1 + k][0], ev[1 + k][1]);
     if (e != hipSuccess) return e;
   }
   return rn_launch_nn_dense(g, m, tb, st, ev[4][0], ev[4][1]);
