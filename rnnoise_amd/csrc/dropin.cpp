@@ -308,6 +308,9 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
 bool comb_submit(StatePool *p, PooledRef *r) {
   Combiner &c = p->comb;
   static const uint64_t gather_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_GATHER_US", 15)) * 1000ull;
+  // $RNNOISE_AMD_COMBINE_LINGER_US: with other groups in flight (the GPU is busy anyway), a caller that could launch waits this
+  // long for more requests to join its group -- fewer, larger groups, so that a stream is free more often when a request arrives
+  static const uint64_t linger_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_LINGER_US", 0)) * 1000ull;
   static const int spin_us = env_int("RNNOISE_AMD_COMBINE_SPIN_US", 400);
   struct Active {
     std::atomic<int> &a;
@@ -343,6 +346,19 @@ bool comb_submit(StatePool *p, PooledRef *r) {
       lk.lock();
       c.gathering = false;
       k = comb_free_stream(p);
+    }
+    if (k >= 0 && linger_ns && !c.gathering) {
+      bool busy = false;
+      for (int i = 0; i < c.n_streams; i++) busy |= c.busy[i];
+      if (busy) {
+        const uint64_t t0 = now_ns();
+        c.gathering = true;
+        lk.unlock();
+        while (now_ns() - t0 < linger_ns) cpu_relax();
+        lk.lock();
+        c.gathering = false;
+        k = comb_free_stream(p);
+      }
     }
     if (k >= 0 && __atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) {  // lead: the whole queue is this group
       comb_take_queue(c, k, grp);

@@ -204,7 +204,7 @@ struct CombMember {
                  // before the group's owner has retired the old entry)
 };
 struct Combiner {
-  static constexpr int MAXG = 4;
+  static constexpr int MAXG = 8;
   std::mutex mu;
   int n_streams = 0;                       // streams created so far (at most $RNNOISE_AMD_COMBINE_STREAMS)
   hipStream_t stream[MAXG] = {};
