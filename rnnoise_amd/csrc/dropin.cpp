@@ -308,9 +308,9 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
 bool comb_submit(StatePool *p, PooledRef *r) {
   Combiner &c = p->comb;
   static const uint64_t gather_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_GATHER_US", 15)) * 1000ull;
-  // $RNNOISE_AMD_COMBINE_LINGER_US: with other groups in flight (the GPU is busy anyway), a caller that could launch waits this
+  // $RNNOISE_AMD_COMBINE_LINGER_US (10): with other groups in flight (the GPU is busy anyway), a caller that could launch waits this
   // long for more requests to join its group -- fewer, larger groups, so that a stream is free more often when a request arrives
-  static const uint64_t linger_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_LINGER_US", 0)) * 1000ull;
+  static const uint64_t linger_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_LINGER_US", 10)) * 1000ull;
   static const int spin_us = env_int("RNNOISE_AMD_COMBINE_SPIN_US", 400);
   struct Active {
     std::atomic<int> &a;
