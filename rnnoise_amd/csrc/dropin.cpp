@@ -212,7 +212,7 @@ void comb_take_queue(Combiner &c, int k, std::vector<CombMember> &grp) {
   }
 }
 
-// one frame step over the rows of `grp`, on stream k of the pool's combiner
+// the four kernels of one frame step over the rows of `grp`, on stream k of the pool's combiner
 int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   RNNoiseBatch *b = p->batch;
   RnRows rows;
@@ -224,12 +224,6 @@ int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   }
   for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
   hipStream_t st = p->comb.stream[k];
-  // one fused launch per group (frame_kernel.hip); $RNNOISE_AMD_FUSED=0: the four latency kernels one after the other (A/B runs)
-  static const bool fused = env_int("RNNOISE_AMD_FUSED", 1) != 0;
-  if (fused) {
-    HIP_OK(rn_launch_frame_rows(&b->g, &b->m, &b->tb, &rows, st));
-    return 0;
-  }
   HIP_OK(rn_launch_hp_rows(&b->g, &rows, st));
   HIP_OK(rn_launch_analysis_rows(&b->g, &b->tb, &rows, st));
   HIP_OK(rn_launch_nn_rows(&b->g, &b->m, &b->tb, &rows, st));

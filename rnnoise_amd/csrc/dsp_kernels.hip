@@ -596,7 +596,7 @@ struct AnalysisLds {
 #endif
 template <bool TRAIN, int SPW>
 __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot_arg, int parity,
-                                              const RnTrainArgs &tr, int listed_row = -1, int lds_off = 0) {
+                                              const RnTrainArgs &tr, int listed_row = -1) {
   const int slot = slot_arg & 255;
   const int k1_stop = RN_INSTRUMENT ? (slot_arg >> 16) : 0;
   (void)k1_stop;
@@ -610,7 +610,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw + lds_off);  // (lds_off: the fused frame kernel keeps other stages' LDS in front)
+  AnalysisLds *arenas = reinterpret_cast<AnalysisLds *>(smem_raw);
   const int wave = SPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, lane = threadIdx.x & (WAVE - 1);
   AnalysisLds &L = arenas[wave];
   float *mail = L.a + SCR_MAIL;
@@ -1220,7 +1220,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
 }
 
-#ifndef RN_FUSED_BUILD  // (frame_kernel.hip includes this file for analysis_body and synthesis_body only)
 // (4 waves per SIMD is what the LDS allows: 16 arenas of 10 KB per CU; without the cap the allocator spreads to 154 VGPRs)
 extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
@@ -1249,7 +1248,6 @@ extern "C" __global__ void __launch_bounds__(WAVE)
 rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnTrainArgs tr) {
   analysis_body<true, 1>(g, tb, slot, parity, tr);
 }
-#endif  // RN_FUSED_BUILD
 
 
 struct SynthLds {
@@ -1270,15 +1268,19 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 // Hermitian-extended spectrum passes once through LDS (natural order in, 15 consecutive bins out per lane) and the time
 // samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
-// One wave, stream s.  `out_row`: the stream's output frame -- float, or int16 when out_s16, written with the truncating
-// conversion of the reference's only caller (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it:
-// cvttss2si to 32 bits -- "integer indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits).  done_word: the
-// completion word of a listed row's request (rn_dev.h: RnRows), or null.
-__device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTablesDev &tb, void *out_row, bool out_s16, int s, int parity,
-                                               int prev, uint32_t *done_word, uint32_t done_value, int lds_off = 0) {
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
+  // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
+  // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
+  // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
+  const bool listed = rows.n > 0;  // a launch group of the one-frame API (rn_dev.h: RnRows)
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  const int parity = listed ? (int)((re >> 12) & 3u) : (parity_arg & 255);
+  const int prev = listed ? (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS : prev_arg;
+  const bool out_s16 = !listed && (parity_arg & 256);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw + lds_off);
-  const int lane = threadIdx.x & (WAVE - 1), pos = fft_pos(lane);
+  SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
+  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
@@ -1402,7 +1404,7 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
   }
   regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));
   // window + overlap-add (src/denoise.c:400-407), straight from the registers
-  float *o = static_cast<float *>(out_row);
+  float *o = listed ? rows.io + (size_t)s * RN_ROW_IO + RN_FRAME_SIZE + 4 : out + (size_t)s * RN_FRAME_SIZE;
 #pragma unroll
   for (int b = 0; b < 15; b++) {
     const int p = WAVE * b + pos;
@@ -1414,7 +1416,7 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
       const float r = v + smv[b];
       if (out_s16) {
         const int q = (r >= -2147483648.f && r < 2147483648.f) ? (int)r : (int)0x80000000;
-        static_cast<short *>(out_row)[n] = (short)q;
+        reinterpret_cast<short *>(out)[(size_t)s * RN_FRAME_SIZE + n] = (short)q;
       } else {
         o[n] = r;
       }
@@ -1422,32 +1424,14 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
       sm[RN_FRAME_SIZE - p] = v;
     }
   }
-  if (done_word) {
+  if (listed) {
     // completion word of the row's request (the last word of its pinned block): the caller waiting for this frame polls it
     // instead of waiting for the whole stream to drain.  System-scope release: the frame and the VAD are visible before it.
     __threadfence_system();
-    if (lane == 0) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(rows.io + (size_t)s * RN_ROW_IO + RN_ROW_IO - 1), re >> 16,
+                                      __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-#ifndef RN_FUSED_BUILD
-extern "C" __global__ void __launch_bounds__(WAVE)
-rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
-  // bit 8 of parity_arg: `out` holds int16 samples
-  if (rows.n > 0) {  // a launch group of the one-frame API (rn_dev.h: RnRows)
-    const uint32_t re = rows.e[blockIdx.x];
-    const int s = (int)(re & 255u), parity = (int)((re >> 12) & 3u);
-    float *row = rows.io + (size_t)s * RN_ROW_IO;
-    synthesis_body(g, tb, row + RN_FRAME_SIZE + 4, false, s, parity, (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS,
-                   reinterpret_cast<uint32_t *>(row + RN_ROW_IO - 1), re >> 16);
-    return;
-  }
-  const int s = blockIdx.x;
-  const bool out_s16 = parity_arg & 256;
-  void *out_row = out_s16 ? static_cast<void *>(reinterpret_cast<short *>(out) + (size_t)s * RN_FRAME_SIZE)
-                          : static_cast<void *>(out + (size_t)s * RN_FRAME_SIZE);
-  synthesis_body(g, tb, out_row, out_s16, s, parity_arg & 255, prev_arg, nullptr, 0);
-}
-
 
 // host-visible launch helpers -----------------------------------------------------------------
 // (K0 lives in hp_kernel.hip; K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream)
@@ -1496,4 +1480,3 @@ extern "C" hipError_t rn_launch_synthesis_rows(const RnGroupDev *g, const RnTabl
   hipLaunchKernelGGL(rn_synthesis_kernel, dim3(rows->n), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, static_cast<float *>(nullptr), 0, 0, *rows);
   return hipGetLastError();
 }
-#endif  // RN_FUSED_BUILD

@@ -10,7 +10,6 @@
 
 #define WAVE 64
 
-#ifndef RN_FUSED_BUILD  // (frame_kernel.hip includes this file for hp_one_body only)
 // ---------------------------------------------------------------------------------------------
 // K0: rnn_biquad (src/denoise.c:409-419, coefficients :469-470), transposed: lane = stream.
 // The recurrence is strictly serial per stream (every step rounds its state to float), so the
@@ -183,8 +182,6 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   }
 }
 
-#endif  // RN_FUSED_BUILD
-
 // ---------------------------------------------------------------------------------------------
 // K0 for a handful of streams (the one-stream states behind rnnoise_process_frame, and batches of up to 64 streams): the
 // same arithmetic with ONE WAVE PER STREAM instead of one lane, arranged for latency.  What is serial stays serial -- the
@@ -199,17 +196,14 @@ struct HpOneLds {
   float xlp[864 + 64 + 8];      // decimated signal (+ room for the reads of the idle lanes of the lag chains)
 };
 
-// One wave, stream s: `in_row` the frame (float, or int16 at the same sample offset when in_s16), L the wave's 12.5 KB of LDS.
-// The hand-offs between the lanes of the wave are wavefront-scope fences (HP_WSYNC): the body runs as a one-wave workgroup
-// (rn_hp_one_kernel) and as wave 0 of the fused frame kernel (frame_kernel.hip), where a workgroup barrier would be wrong.
-#define HP_WSYNC()                                             \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
-  } while (0)
-__device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__restrict__ in_row, int s, int slot, int in_s16, HpOneLds &L,
-                                            int lane) {
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
+  __shared__ __attribute__((aligned(16))) HpOneLds L;
+  // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
+  const bool listed = rows.n > 0;
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, slot = listed ? (int)((re >> 8) & 7u) : slot_arg, lane = threadIdx.x;
+  const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO : in + (size_t)s * RN_FRAME_SIZE;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
@@ -217,7 +211,7 @@ __device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__
   const int ring0 = RN_RING0(slot);
   {  // frame -> xin (120 float4), old part of pitch_buf -> pb (312 float4; ring0 and the ring size are multiples of 32)
     const float4 *x = reinterpret_cast<const float4 *>(in_row);
-    const short4 *x16 = reinterpret_cast<const short4 *>(in_row);  // (int16 frames: the caller passes the row's int16 address)
+    const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
     float4 f[2], o[5];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -243,7 +237,7 @@ __device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__
     for (int i = 0; i < 5; i++)
       if (lane + 64 * i < (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
   }
-  HP_WSYNC();
+  __syncthreads();
   // rnn_biquad (src/denoise.c:409-419), once per wave: every lane reads the same samples and computes the same states
   {
     const float4 *xi4 = reinterpret_cast<const float4 *>(L.xin);
@@ -281,7 +275,7 @@ __device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__
       g.mem_hp[2 * s + 1] = m1;
     }
   }
-  HP_WSYNC();
+  __syncthreads();
   {  // the filtered frame -> its ring slot (coalesced); 2x decimation of the whole pitch_buf (src/pitch.c:155-160)
     float4 *y = reinterpret_cast<float4 *>(ring + slot * RN_FRAME_SIZE);
     const float4 *src = reinterpret_cast<const float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE));
@@ -299,7 +293,7 @@ __device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__
     if (lane < 8) L.xlp[864 + lane] = 0;
     L.xlp[872 + lane] = 0;
   }
-  HP_WSYNC();
+  __syncthreads();
   // 5-lag autocorrelation (src/celt_lpc.c:92-174): lane k = lag k, terms in the reference's order; terms i >= 860 form the
   // tail chain d (rnn_pitch_xcorr runs over fastN = 860 terms, the rest is added afterwards)
   float acl = 0, dl = 0;
@@ -364,20 +358,6 @@ __device__ __forceinline__ void hp_one_body(const RnGroupDev &g, const float *__
 }
 
 
-#ifndef RN_FUSED_BUILD
-extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
-  __shared__ __attribute__((aligned(16))) HpOneLds L;
-  // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
-  const bool listed = rows.n > 0;
-  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
-  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, slot = listed ? (int)((re >> 8) & 7u) : slot_arg;
-  const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO
-                               : (in_s16 ? reinterpret_cast<const float *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE)
-                                         : in + (size_t)s * RN_FRAME_SIZE);
-  hp_one_body(g, in_row, s, slot, in_s16, L, threadIdx.x);
-}
-
 // (up to RN_HP_ONE_MAX streams one wave per stream is the faster form -- measured K0 at 256 / 1024 / 2048 / 4096 streams: 24 / 26 / 35 / 66 us
 // against 55 / 55 / 55 / 59 us lane = stream: its 12.5 KB of LDS per wave limit a CU to 12 waves)
 #define RN_HP_ONE_MAX 3072
@@ -400,4 +380,3 @@ extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *g, const RnRows *rows,
   hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), 0, 0, *rows);
   return hipGetLastError();
 }
-#endif  // RN_FUSED_BUILD

@@ -175,7 +175,6 @@ struct NnLds {
   int hq[96];       // quantised recurrent state
 };
 
-#ifndef RN_FUSED_BUILD
 extern "C" __global__ void __launch_bounds__(NN_THREADS)
 rn_nn_vector_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
   __shared__ NnLds L;
@@ -255,8 +254,6 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *g, const RnModelDev 
   return hipGetLastError();
 }
 
-#endif  // RN_FUSED_BUILD
-
 // ---------------------------------------------------------------------------------------------
 // K2 for a handful of streams (the one-stream states behind rnnoise_process_frame, include/rnnoise.h:94, and batches of up to
 // 512 streams): the same network and the same bits as rn_nn_vector_kernel, arranged for LATENCY.  One workgroup of 14 waves
@@ -303,25 +300,15 @@ __device__ __forceinline__ unsigned one_lds_addr(const void *p) {
 __device__ __forceinline__ int one_pair_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
 __device__ __forceinline__ float one_pair_f(float v) { return __int_as_float(one_pair_i(__float_as_int(v))); }
 
-// What the network's first phases consume from LDS and nothing in the frame produces -- conv1's 195 x 128 matrix (98 pieces of
-// 1 KB; the last piece's tail lanes re-read the last 16 bytes), the rcpps table (8), vad_dense's weights (6) -- by LDS-DMA,
-// piece p by wave p mod npw of the npw waves that take part (pw = this wave's number among them).  The stand-alone kernel
-// does it first thing; the fused frame kernel (frame_kernel.hip) has its idle waves do it while wave 0 is still filtering.
-__device__ __forceinline__ void nn_one_prefetch(const RnModelDev &m, const RnTablesDev &tb, OneLds &O, int pw, int npw, int lane) {
-  constexpr int last = RN_CONV1_K * 128 * 4 - 16;
-  for (int p = pw; p < 98 + 8 + RN_CAT * 4 / 1024; p += npw) {  // (wave-uniform)
-    if (p < 98) one_dma_1k(reinterpret_cast<const char *>(m.conv1.fw) + min(p * 1024 + lane * 16, last), one_lds_addr(O.big) + p * 1024);
-    else if (p < 106) one_dma_1k(reinterpret_cast<const char *>(tb.rcp16) + (p - 98) * 1024 + lane * 16, one_lds_addr(O.lut) + (p - 98) * 1024);
-    else one_dma_1k(reinterpret_cast<const char *>(m.vad_dense.fw) + (p - 106) * 1024 + lane * 16, one_lds_addr(O.vadw) + (p - 106) * 1024);
-  }
-}
-
-// the network for stream s on the 14 waves of the workgroup (every wave calls this; it contains workgroup barriers).
-// vad_dst: where the VAD probability goes.  prefetched: nn_one_prefetch has been issued (and waited for) by the caller's waves.
-__device__ __forceinline__ void nn_one_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int s, float *vad_dst, OneLds &O,
-                                            bool prefetched) {
+extern "C" __global__ void __launch_bounds__(ONE_THREADS)
+rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
+  extern __shared__ __attribute__((aligned(16))) char one_smem[];
+  OneLds &O = *reinterpret_cast<OneLds *>(one_smem);
   NnLds &L = O.n;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // (rows: a launch group of the one-frame API, rn_dev.h -- the block's pool row, its VAD goes to the row's pinned frame block)
+  const bool listed = rows.n > 0;
+  const int s = listed ? (int)(rows.e[blockIdx.x] & 255u) : (int)blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float *vad_dst = listed ? rows.io + (size_t)s * RN_ROW_IO + 2 * RN_FRAME_SIZE + 4 : g.vad + s;
   const bool chain_wave = t >= ONE_ROW_THREADS;  // waves 12 (dense_out) and 13 (vad_dense)
   const bool vad_wave = wave == 13;
   const int ct = lane & 31;                      // wave 12: dense_out output of this lane (the upper half repeats the lower)
@@ -345,8 +332,22 @@ __device__ __forceinline__ void nn_one_body(const RnGroupDev &g, const RnModelDe
 #else
 #define ONE_TAP() do { } while (0)
 #endif
-  {
-    if (!prefetched) nn_one_prefetch(m, tb, O, wave, ONE_THREADS / 64, lane);
+  {  // conv1 weights -> LDS: 98 pieces of 1 KB over 13 waves (the last piece's tail lanes re-read the last 16 bytes)
+    const char *src = reinterpret_cast<const char *>(m.conv1.fw);
+    const unsigned dst = one_lds_addr(O.big);
+    constexpr int last = RN_CONV1_K * 128 * 4 - 16;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      const int piece = wave + 14 * i;  // wave-uniform; 14 x 7 = 98
+      one_dma_1k(src + min(piece * 1024 + lane * 16, last), dst + piece * 1024);
+    }
+    if (vad_wave) {
+#pragma unroll
+      for (int i = 0; i < RN_CAT * 4 / 1024; i++)
+        one_dma_1k(reinterpret_cast<const char *>(m.vad_dense.fw) + i * 1024 + lane * 16, one_lds_addr(O.vadw) + i * 1024);
+    } else if (wave < 8) {
+      one_dma_1k(reinterpret_cast<const char *>(tb.rcp16) + wave * 1024 + lane * 16, one_lds_addr(O.lut) + wave * 1024);
+    }
     if (t < 130) L.tmp1[t] = c1s[t];
     if (t < 65) L.tmp1[130 + t] = g.features[(size_t)s * 68 + t];
     if (t >= 128 && t < RN_GRU) L.tmp2[t - 128] = c2s[t - 128];  // 256 history values
@@ -525,17 +526,6 @@ __device__ __forceinline__ void nn_one_body(const RnGroupDev &g, const RnModelDe
 #undef ONE_TAP
 }
 
-#ifndef RN_FUSED_BUILD  // (frame_kernel.hip includes this file for nn_one_body only)
-extern "C" __global__ void __launch_bounds__(ONE_THREADS)
-rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
-  extern __shared__ __attribute__((aligned(16))) char one_smem[];
-  OneLds &O = *reinterpret_cast<OneLds *>(one_smem);
-  // (rows: a launch group of the one-frame API, rn_dev.h -- the block's pool row, its VAD goes to the row's pinned frame block)
-  const bool listed = rows.n > 0;
-  const int s = listed ? (int)(rows.e[blockIdx.x] & 255u) : (int)blockIdx.x;
-  nn_one_body(g, m, tb, s, listed ? rows.io + (size_t)s * RN_ROW_IO + 2 * RN_FRAME_SIZE + 4 : g.vad + s, O, false);
-}
-
 // the 125 KB of dynamic LDS are an opt-in per DEVICE (a process may hold pools and batches on several GPUs): once per device,
 // on the device the launch goes to
 static hipError_t nn_one_opt_in() {
@@ -567,4 +557,3 @@ extern "C" hipError_t rn_launch_nn_rows(const RnGroupDev *g, const RnModelDev *m
 }
 
 // MFMA path: see nn_mfma.hip
-#endif  // RN_FUSED_BUILD

@@ -60,7 +60,6 @@ extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *, const RnRows *, hipS
 extern "C" hipError_t rn_launch_analysis_rows(const RnGroupDev *, const RnTablesDev *, const RnRows *, hipStream_t);
 extern "C" hipError_t rn_launch_nn_rows(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, const RnRows *, hipStream_t);
 extern "C" hipError_t rn_launch_synthesis_rows(const RnGroupDev *, const RnTablesDev *, const RnRows *, hipStream_t);
-extern "C" hipError_t rn_launch_frame_rows(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, const RnRows *, hipStream_t);
 
 // Every entry point works on the batch's device and leaves the calling thread's current device as it found it
 // (a host thread may be driving another GPU: torch on cuda:0 beside a batch on device 1).
