@@ -49,6 +49,12 @@ __device__ __forceinline__ v4f_ lds_read16(ldsf p) { return *(const LDS_AS v4f_ 
 // fuses neighbouring ones into ds_read2_b64, which the LDS serves at half that rate (8 cycles per instruction,
 // MI355X_MICROARCH.md section LDS) -- in the chains below that doubled the cycles of the operand stream.
 __device__ __forceinline__ v2f lds_read8(ldsf p) { return *(const volatile LDS_AS v2f *)p; }
+// lane K of each 16-lane row to every lane of the row: as an operand of an arithmetic instruction it folds into the instruction
+// (v_..._dpp row_newbcast:K); the SOURCE lane must be active
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {  // lane K of each 16-lane row to every lane of the row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, true));
+}
 
 // Band energy / correlation (src/denoise.c:90-138).  The reference's interleaved loop adds, for
 // every bin of band b, (1-frac)*tmp to sum[b] and frac*tmp to sum[b+1]; so accumulator k receives
@@ -281,40 +287,114 @@ __device__ __forceinline__ void energy_sweeps_run(float *rsq, float *D, const fl
     b = bn;
   }
 }
-// The same two recurrences as functions of their own, one lane per stream each, for workgroups whose narrow phases are spread
-// over the waves (analysis_body): the fine Syy sweep and yy_lookup then advance at the same time on two SIMDs, and each
-// sheds the operation the shared form carried for the other's sake -- (s + a) - 0 == s + a and max(-inf, x) == x, so the
-// stored bits are those of energy_sweeps_run for every non-NaN operand.
-__device__ __forceinline__ void sweep_syy_fine(float *D, float syy0) {
-  D[-1] = syy0;
-  float s = syy0;
-  float4 a = *reinterpret_cast<const float4 *>(D);
-  for (int j = 0; j < 296; j += 4) {
-    const float4 an = *reinterpret_cast<const float4 *>(D + (j + 4 < 296 ? j + 4 : j));
-    float4 o;
-    s = fmaxf(1.f, s + a.x); o.x = s;
-    s = fmaxf(1.f, s + a.y); o.y = s;
-    s = fmaxf(1.f, s + a.z); o.z = s;
-    s = fmaxf(1.f, s + a.w); o.w = s;
-    *reinterpret_cast<float4 *>(D + j) = o;
+// The same two recurrences as functions of their own for workgroups whose narrow phases are spread over the waves
+// (analysis_body): the fine Syy sweep and yy_lookup then advance at the same time on two SIMDs, and each sheds the operation
+// the shared form carried for the other's sake -- (s + a) - 0 == s + a and max(-inf, x) == x, so the stored bits are those of
+// energy_sweeps_run for every non-NaN operand.  One ROW of 16 lanes per stream: the row fetches 64 steps' operands in one
+// 16-byte read per lane (lane k: steps 4k .. 4k+3) a whole block ahead, and every lane of the row runs the chain, taking step
+// operands from lane k's registers as DPP operands (row_newbcast:k) -- the chain wave shares its CU's LDS pipe with fifteen
+// waves in their wide phases, and with one small read per four steps the recurrence spent more time waiting for LDS round
+// trips than adding (11 k cycles for 768 dependent instructions; profiles/r4_k1_narrow.txt).  All lanes of a row hold the same
+// value and store it to the same address every four steps.
+typedef LDS_AS float *ldsfw;
+template <int K>
+struct SyyRowSteps {
+  static __device__ __forceinline__ void run(float &s, const v4f_ &a, ldsfw out, bool store) {
+    v4f_ o;
+    s = fmaxf(1.f, s + row_bcast<K>(a.x)); o.x = s;
+    s = fmaxf(1.f, s + row_bcast<K>(a.y)); o.y = s;
+    s = fmaxf(1.f, s + row_bcast<K>(a.z)); o.z = s;
+    s = fmaxf(1.f, s + row_bcast<K>(a.w)); o.w = s;
+    if (store) *(LDS_AS v4f_ *)(out + 4 * K) = o;
+    SyyRowSteps<K + 1>::run(s, a, out, store);
+  }
+};
+template <>
+struct SyyRowSteps<16> {
+  static __device__ __forceinline__ void run(float &, const v4f_ &, ldsfw, bool) {}
+};
+template <int K>
+struct YyRowSteps {
+  static __device__ __forceinline__ void run(float &s, const v4f_ &a, const v4f_ &b, ldsfw out, bool store) {
+    v4f_ o;
+    s = (s + row_bcast<K>(a.x)) - row_bcast<K>(b.x); o.x = s;
+    s = (s + row_bcast<K>(a.y)) - row_bcast<K>(b.y); o.y = s;
+    s = (s + row_bcast<K>(a.z)) - row_bcast<K>(b.z); o.z = s;
+    s = (s + row_bcast<K>(a.w)) - row_bcast<K>(b.w); o.w = s;
+    if (store) *(LDS_AS v4f_ *)(out + 4 * K) = o;
+    YyRowSteps<K + 1>::run(s, a, b, out, store);
+  }
+};
+template <>
+struct YyRowSteps<16> {
+  static __device__ __forceinline__ void run(float &, const v4f_ &, const v4f_ &, ldsfw, bool) {}
+};
+// the coarse running energy (fbp_sweep) the same way: syy[i] holds the increment of step i going in and Syy BEFORE step i coming
+// out, i < 148; three blocks of 64 (the 44 steps past the end run on whatever the dead area behind holds and land there)
+template <int K>
+struct SyyBeforeRowSteps {
+  static __device__ __forceinline__ void run(float &s, const v4f_ &a, ldsfw out) {
+    v4f_ o;
+    o.x = s; s = fmaxf(1.f, s + row_bcast<K>(a.x));
+    o.y = s; s = fmaxf(1.f, s + row_bcast<K>(a.y));
+    o.z = s; s = fmaxf(1.f, s + row_bcast<K>(a.z));
+    o.w = s; s = fmaxf(1.f, s + row_bcast<K>(a.w));
+    *(LDS_AS v4f_ *)(out + 4 * K) = o;
+    SyyBeforeRowSteps<K + 1>::run(s, a, out);
+  }
+};
+template <>
+struct SyyBeforeRowSteps<16> {
+  static __device__ __forceinline__ void run(float &, const v4f_ &, ldsfw) {}
+};
+__device__ __forceinline__ void fbp_sweep_row(float *syy, float Syy0, int l16) {
+  float s = Syy0;
+  ldsfw d = (ldsfw)syy;
+  v4f_ a = *(const LDS_AS v4f_ *)(d + 4 * l16);
+#pragma unroll 1
+  for (int j = 0; j < 192; j += 64) {
+    const v4f_ an = *(const LDS_AS v4f_ *)(d + (j + 64 < 192 ? j + 64 : j) + 4 * l16);
+    SyyBeforeRowSteps<0>::run(s, a, d + j);
     a = an;
   }
 }
-__device__ __forceinline__ void sweep_yy_lookup(float *rsq, float xx) {
+// D: [-1..295] of the row's stream (16-byte aligned at D[0]); every lane of the wave takes part, l16 = lane & 15
+__device__ __forceinline__ void sweep_syy_fine_row(float *D, float syy0, int l16) {
+  D[-1] = syy0;
+  float s = syy0;
+  ldsfw d = (ldsfw)D;
+  v4f_ a = *(const LDS_AS v4f_ *)(d + 4 * l16);
+#pragma unroll 1
+  for (int j = 0; j < 320; j += 64) {  // 296 steps: four whole blocks and 40 steps of a fifth
+    const v4f_ an = *(const LDS_AS v4f_ *)(d + (j + 64 < 320 ? j + 64 : j) + 4 * l16);  // (past 295: the xcorr area, read and never used)
+    if (j < 256) {
+      SyyRowSteps<0>::run(s, a, d + j, true);
+    } else {  // steps 256 .. 295: ten of the sixteen groups
+      v4f_ o;
+#define SYY_G(K)                                              \
+      s = fmaxf(1.f, s + row_bcast<K>(a.x)); o.x = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.y)); o.y = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.z)); o.z = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.w)); o.w = s;         \
+      *(LDS_AS v4f_ *)(d + j + 4 * K) = o;
+      SYY_G(0) SYY_G(1) SYY_G(2) SYY_G(3) SYY_G(4) SYY_G(5) SYY_G(6) SYY_G(7) SYY_G(8) SYY_G(9)
+#undef SYY_G
+    }
+    a = an;
+  }
+}
+// rsq: the 864 reversed squares of the row's stream (energy_sweeps_prepare); results as energy_sweeps_run leaves them
+__device__ __forceinline__ void sweep_yy_lookup_row(float *rsq, float xx, int l16, bool store = true) {
   rsq[479] = xx;
   float s = xx;
-  float *pa = rsq + 480;
-  const float *pb = rsq;
-  float4 a = *reinterpret_cast<const float4 *>(pa), b = *reinterpret_cast<const float4 *>(pb);
-  for (int j = 0; j < 384; j += 4) {
-    const float4 an = *reinterpret_cast<const float4 *>(pa + j + 4);  // last one reads past the operands (inside the arena); unused
-    const float4 bn = *reinterpret_cast<const float4 *>(pb + j + 4);
-    float4 o;
-    s = (s + a.x) - b.x; o.x = s;
-    s = (s + a.y) - b.y; o.y = s;
-    s = (s + a.z) - b.z; o.z = s;
-    s = (s + a.w) - b.w; o.w = s;
-    *reinterpret_cast<float4 *>(pa + j) = o;
+  ldsfw pa = (ldsfw)rsq + 480, pb = (ldsfw)rsq;
+  v4f_ a = *(const LDS_AS v4f_ *)(pa + 4 * l16), b = *(const LDS_AS v4f_ *)(pb + 4 * l16);
+#pragma unroll 1
+  for (int j = 0; j < 384; j += 64) {
+    const int jn = j + 64 < 384 ? j + 64 : j;
+    const v4f_ an = *(const LDS_AS v4f_ *)(pa + jn + 4 * l16), bn = *(const LDS_AS v4f_ *)(pb + jn + 4 * l16);
+    YyRowSteps<0>::run(s, a, b, pa + j, store);
+    if (!store) asm volatile("" ::"v"(s));  // (timing experiment: keep the chain alive)
     a = an;
     b = bn;
   }
@@ -440,10 +520,6 @@ __device__ __forceinline__ float chain_dot8_y2(ldsf x, ldsf y2, int n) {
 // A DPP operand reads the register of another LANE, which must be active: callers run this with all 64 lanes (lanes without a
 // chain of their own compute a dummy one).  n a multiple of 16.
 template <int K>
-__device__ __forceinline__ float row_bcast(float v) {  // lane K of each 16-lane row to every lane of the row
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xF, 0xF, true));
-}
-template <int K>
 struct ChainSteps {
   static __device__ __forceinline__ void run(float &s, float xr, const v2f (&y)[8]) {
     float p = row_bcast<K>(xr) * ((K & 1) ? y[K >> 1].y : y[K >> 1].x);
@@ -456,23 +532,43 @@ template <>
 struct ChainSteps<16> {
   static __device__ __forceinline__ void run(float &, float, const v2f (&)[8]) {}
 };
+// DEEP: operands TWO blocks of 16 steps ahead instead of one (16 more registers).  The narrow phase's chain wave shares its CU's
+// LDS pipe with fifteen waves in their wide phases: one block ahead (~170 cycles of chain) does not cover an LDS round trip
+// there, and the chain waited for operands at every block (9 k of its 11.5 k cycles).
+template <bool DEEP>
 __device__ __forceinline__ float chain_dot16_xrow(ldsf x, ldsf y2, int n, int lane) {
   float s = 0.f;
   ldsf xl = x + (lane & 15);
-  float xr = *xl;
-  v2f ya[8];
+  float xr = *xl, xm = 0.f;
+  v2f ya[8], ym[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) ya[k] = lds_read8(y2 + 2 * k);
+  if (DEEP) {
+    xm = xl[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ym[k] = lds_read8(y2 + 16 + 2 * k);
+  }
   for (int i = 0; i < n; i += 16) {
-    const int nx = (i + 16 < n) ? i + 16 : i;
+    const int ahead = DEEP ? 32 : 16;
+    const int nx = (i + ahead < n) ? i + ahead : i;
     const float xn = xl[nx];
     v2f yn[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) yn[k] = lds_read8(y2 + nx + 2 * k);
     ChainSteps<0>::run(s, xr, ya);
-    xr = xn;
+    if (DEEP) {
+      xr = xm;
+      xm = xn;
 #pragma unroll
-    for (int k = 0; k < 8; k++) ya[k] = yn[k];
+      for (int k = 0; k < 8; k++) {
+        ya[k] = ym[k];
+        ym[k] = yn[k];
+      }
+    } else {
+      xr = xn;
+#pragma unroll
+      for (int k = 0; k < 8; k++) ya[k] = yn[k];
+    }
   }
   return s;
 }
@@ -605,7 +701,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // the waves (and so over the SIMDs: a workgroup's waves sit on different SIMDs) instead of making wave 0 the straggler of
   // every workgroup, and the two running-energy sweeps of phase 3 advance side by side.  Clear: everything on wave 0 (round 3).
   const bool spread = SPW > 1 && (slot_arg & 512);
-  const bool xrow = !(slot_arg & 1024);  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
+  const bool xrow = !(slot_arg & 1024);
+  const int narrow_prio = (slot_arg & 4096) ? 1 : 3;      // bit 12 (A/B runs): the narrow-phase waves keep the kernel's priority
+  const bool narrow_timing_only = slot_arg & 2048;        // bit 11 (timing experiments ONLY, wrong results): phase 3 skipped
+  const bool sweep_no_stores = slot_arg & 8192;           // bit 13 (timing experiments ONLY, wrong results): phase 3 without its LDS stores  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -795,8 +894,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // slot it can use (a lone wave issues once per ~5 cycles whatever its priority; profiles/r3_valu_issue.txt) ahead of the
     // three waves of other workgroups on its SIMD, which have independent work for the remaining slots.
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
-    const int gi = lane < SPW ? lane : 0;
-    fbp_sweep(arenas[gi].a + SCR_SYY, 147, arenas[gi].a[SCR_MAIL + MAIL_SYY0C], lane < SPW);
+    if (spread) {  // one row of 16 lanes per stream (see sweep_syy_fine_row)
+      float *ag = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+      fbp_sweep_row(ag + SCR_SYY, ag[SCR_MAIL + MAIL_SYY0C], lane & 15);
+    } else {
+      const int gi = lane < SPW ? lane : 0;
+      fbp_sweep(arenas[gi].a + SCR_SYY, 147, arenas[gi].a[SCR_MAIL + MAIL_SYY0C], lane < SPW);
+    }
     if (SPW > 1) __builtin_amdgcn_s_setprio(1);
   }
   WG_SYNC();
@@ -835,19 +939,19 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // group were mostly bank conflicts.  Wave nw3a, at the same time on another SIMD: the start energy 1 + sum x_lp[j]^2
     // of the fine find_best_pitch of every stream, one lane each -- the value its own sweep of phase 3 starts from.
     if (wave == nw2) {
-      __builtin_amdgcn_s_setprio(3);
+      if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
       const int gq = lane >> 4, r = lane & 15;  // (SPW == 4 rows)
       float *ag = arenas[gq < SPW ? gq : 0].a;
       const int b0 = __float_as_int(ag[SCR_MAIL + MAIL_BP0]), b1 = __float_as_int(ag[SCR_MAIL + MAIL_BP1]);
       const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
       const bool lag = r < 10 && c >= 0 && c < 294;
       const int a = lag ? c : 384;
-      const float sum = chain_dot16_xrow(to_lds(ag + SCR_XLP + 384), to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), 480, lane);
+      const float sum = chain_dot16_xrow<true>(to_lds(ag + SCR_XLP + 384), to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), 480, lane);
       if (lag) ag[SCR_XC + c] = (-1 > sum) ? -1 : sum;
       if (r == 10) ag[SCR_MAIL + MAIL_XX] = sum;
       __builtin_amdgcn_s_setprio(1);
     } else if (wave == nw3a) {
-      __builtin_amdgcn_s_setprio(3);
+      if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
       if (lane < SPW) {
         float *ag = arenas[lane].a;
         ag[SCR_MAIL + MAIL_SYY0F] = chain_sq8(to_lds(ag + SCR_XLP), 480, 1.f);
@@ -856,6 +960,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     // every wave: the operands of the two running-energy sweeps of its own stream, over the shifted copy (dead now)
     __syncthreads();
+    K1_STOP(17);  // (tools/k1_prefix.sh NARROW=1: narrow phase 2 ends here)
     energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
   } else if (wave == 0) {
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
@@ -885,12 +990,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   if (spread) {
     // narrow phase 3, spread: the fine running energy of every stream on one wave, yy_lookup of every stream on another
     __syncthreads();
-    if (wave == nw3a || wave == nw3b) {
-      __builtin_amdgcn_s_setprio(3);
-      if (lane < SPW) {
-        float *a = arenas[lane].a;
-        if (wave == nw3a) sweep_syy_fine(a + SCR_D, a[SCR_MAIL + MAIL_SYY0F]);
-        else sweep_yy_lookup(a + SCR_SQ, a[SCR_MAIL + MAIL_XX]);
+    K1_STOP(18);  // (the sweeps' operands are in place)
+    if ((wave == nw3a || wave == nw3b) && !narrow_timing_only) {
+      if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
+      {  // (every lane takes part: the rows' DPP operands come from the other lanes' registers)
+        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+        if (wave == nw3a) sweep_syy_fine_row(a + SCR_D, a[SCR_MAIL + MAIL_SYY0F], lane & 15);
+        else sweep_yy_lookup_row(a + SCR_SQ, a[SCR_MAIL + MAIL_XX], lane & 15, !sweep_no_stores);
       }
       __builtin_amdgcn_s_setprio(1);
     }
@@ -995,7 +1101,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       // an offset of their own run <x, x>, all of them on the same addresses (a broadcast, not a bank conflict), and drop it
       const int a = maxperiod - (off >= 0 ? off : 0);  // y = x_lp + a
       ldsf ya = to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a));
-      const float d = xrow ? chain_dot16_xrow(to_lds(x), ya, N, lane) : (off >= 0 ? chain_dot8_y2(to_lds(x), ya, N) : 0.f);
+      const float d = xrow ? chain_dot16_xrow<false>(to_lds(x), ya, N, lane) : (off >= 0 ? chain_dot8_y2(to_lds(x), ya, N) : 0.f);
       if (off >= 0) dots[lane] = d;
     }
     RN_WSYNC();
@@ -1053,7 +1159,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       RN_WSYNC();
       {
         const int a = maxperiod - (lane < 2 ? T + (lane ? 1 : -1) : 0);
-        const float d = chain_dot16_xrow(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N, lane);
+        const float d = chain_dot16_xrow<false>(to_lds(x), to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), N, lane);
         if (lane < 2) dots[32 + lane] = d;
       }
       RN_WSYNC();
@@ -1235,12 +1341,12 @@ rn_analysis_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity) {
 // 8192: 17.7 / 19.6, 16,384: 19.0 / 22.1.  (Round 1's 80-VGPR "lean" build no longer pays at any size and is gone.)
 extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnRows rows) {
-  if (rows.n > 0) {  // a launch group of the one-frame API: the block's row at that row's own frame phase
-    const uint32_t re = rows.e[blockIdx.x];
-    analysis_body<false, 1>(g, tb, (int)((re >> 8) & 7u), (int)((re >> 12) & 3u), RnTrainArgs{}, (int)(re & 255u));
-    return;
-  }
-  analysis_body<false, 1>(g, tb, slot, parity, RnTrainArgs{});
+  // (a launch group of the one-frame API: the block's row at that row's own frame phase.  ONE instance of the body: two made the
+  //  kernel 80 KB of code, more than the instruction cache two CUs share)
+  const bool listed = rows.n > 0;
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  analysis_body<false, 1>(g, tb, listed ? (int)((re >> 8) & 7u) : slot, listed ? (int)((re >> 12) & 3u) : parity, RnTrainArgs{},
+                          listed ? (int)(re & 255u) : -1);
 }
 
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
@@ -1452,7 +1558,10 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
     // narrow phases spread over the waves of a workgroup (analysis_body); RNNOISE_AMD_K1_SPREAD=0: all on wave 0 (A/B runs)
     static const int spread = [] { const char *e = getenv("RNNOISE_AMD_K1_SPREAD"); return (e && atoi(e) == 0) ? 0 : 512; }();
-    static const int noxrow = [] { const char *e = getenv("RNNOISE_AMD_K1_XROW"); return (e && atoi(e) == 0) ? 1024 : 0; }();
+    static const int noxrow = [] {
+      const char *e = getenv("RNNOISE_AMD_K1_XROW"), *x = getenv("RNNOISE_AMD_K1_EXPERIMENT");  // (experiment: 2048 / 4096 / both, see analysis_body)
+      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (2048 | 4096 | 8192)) : 0);
+    }();
     RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread | noxrow, parity);
   }
   return hipGetLastError();
