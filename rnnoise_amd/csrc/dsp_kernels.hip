@@ -539,36 +539,47 @@ template <bool DEEP>
 __device__ __forceinline__ float chain_dot16_xrow(ldsf x, ldsf y2, int n, int lane) {
   float s = 0.f;
   ldsf xl = x + (lane & 15);
-  float xr = *xl, xm = 0.f;
-  v2f ya[8], ym[8];
+  if (!DEEP) {
+    float xr = *xl;
+    v2f ya[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) ya[k] = lds_read8(y2 + 2 * k);
-  if (DEEP) {
-    xm = xl[16];
+    for (int k = 0; k < 8; k++) ya[k] = lds_read8(y2 + 2 * k);
+    for (int i = 0; i < n; i += 16) {
+      const int nx = (i + 16 < n) ? i + 16 : i;
+      const float xn = xl[nx];
+      v2f yn[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) ym[k] = lds_read8(y2 + 16 + 2 * k);
-  }
-  for (int i = 0; i < n; i += 16) {
-    const int ahead = DEEP ? 32 : 16;
-    const int nx = (i + ahead < n) ? i + ahead : i;
-    const float xn = xl[nx];
-    v2f yn[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) yn[k] = lds_read8(y2 + nx + 2 * k);
-    ChainSteps<0>::run(s, xr, ya);
-    if (DEEP) {
-      xr = xm;
-      xm = xn;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        ya[k] = ym[k];
-        ym[k] = yn[k];
-      }
-    } else {
+      for (int k = 0; k < 8; k++) yn[k] = lds_read8(y2 + nx + 2 * k);
+      ChainSteps<0>::run(s, xr, ya);
       xr = xn;
 #pragma unroll
       for (int k = 0; k < 8; k++) ya[k] = yn[k];
     }
+    return s;
+  }
+  // two blocks ahead: three operand sets in rotation, the loop body spelled out three blocks at a time so that no set is
+  // ever copied into another (n a multiple of 48)
+  float x0 = xl[0], x1 = xl[16], x2;
+  v2f y0[8], y1[8], y2v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    y0[k] = lds_read8(y2 + 2 * k);
+    y1[k] = lds_read8(y2 + 16 + 2 * k);
+  }
+  for (int i = 0; i < n; i += 48) {
+    const int a = (i + 32 < n) ? i + 32 : i, b = (i + 48 < n) ? i + 48 : i, c = (i + 64 < n) ? i + 64 : i;
+    x2 = xl[a];
+#pragma unroll
+    for (int k = 0; k < 8; k++) y2v[k] = lds_read8(y2 + a + 2 * k);
+    ChainSteps<0>::run(s, x0, y0);
+    x0 = xl[b];
+#pragma unroll
+    for (int k = 0; k < 8; k++) y0[k] = lds_read8(y2 + b + 2 * k);
+    ChainSteps<0>::run(s, x1, y1);
+    x1 = xl[c];
+#pragma unroll
+    for (int k = 0; k < 8; k++) y1[k] = lds_read8(y2 + c + 2 * k);
+    ChainSteps<0>::run(s, x2, y2v);
   }
   return s;
 }
@@ -704,7 +715,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const bool xrow = !(slot_arg & 1024);
   const int narrow_prio = (slot_arg & 4096) ? 1 : 3;      // bit 12 (A/B runs): the narrow-phase waves keep the kernel's priority
   const bool narrow_timing_only = slot_arg & 2048;        // bit 11 (timing experiments ONLY, wrong results): phase 3 skipped
-  const bool sweep_no_stores = slot_arg & 8192;           // bit 13 (timing experiments ONLY, wrong results): phase 3 without its LDS stores  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
+  const bool sweep_no_stores = slot_arg & 8192;           // bit 13 (timing experiments ONLY, wrong results): phase 3 without its LDS stores
+  const bool fine_deep = !(slot_arg & 16384);             // bit 14 (A/B runs): the fine-search chains fetch one block ahead, not two  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -946,7 +958,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
       const bool lag = r < 10 && c >= 0 && c < 294;
       const int a = lag ? c : 384;
-      const float sum = chain_dot16_xrow<true>(to_lds(ag + SCR_XLP + 384), to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a)), 480, lane);
+      ldsf xg = to_lds(ag + SCR_XLP + 384), yg = to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a));
+      const float sum = fine_deep ? chain_dot16_xrow<true>(xg, yg, 480, lane) : chain_dot16_xrow<false>(xg, yg, 480, lane);
       if (lag) ag[SCR_XC + c] = (-1 > sum) ? -1 : sum;
       if (r == 10) ag[SCR_MAIL + MAIL_XX] = sum;
       __builtin_amdgcn_s_setprio(1);
@@ -1560,7 +1573,7 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     static const int spread = [] { const char *e = getenv("RNNOISE_AMD_K1_SPREAD"); return (e && atoi(e) == 0) ? 0 : 512; }();
     static const int noxrow = [] {
       const char *e = getenv("RNNOISE_AMD_K1_XROW"), *x = getenv("RNNOISE_AMD_K1_EXPERIMENT");  // (experiment: 2048 / 4096 / both, see analysis_body)
-      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (2048 | 4096 | 8192)) : 0);
+      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (2048 | 4096 | 8192 | 16384)) : 0);
     }();
     RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread | noxrow, parity);
   }
