@@ -399,6 +399,77 @@ __device__ __forceinline__ void sweep_yy_lookup_row(float *rsq, float xx, int l1
     b = bn;
   }
 }
+// The two sweeps WITHOUT prepared operand arrays (workgroups of several streams): the operands of a block of 64 steps are
+// squares of x_lp samples that the row's lanes hold anyway after one 16-byte read each, so lane k squares the samples of ITS
+// four steps (each product rounded once, the difference of two products rounded once: energy_sweeps_prepare's values) and the
+// chain takes them as DPP operands as above.  Nothing is staged in LDS: the pass that wrote 864 squares and 296 increments per
+// stream is gone, x_lp's shifted copy survives from the fine search to the doubling dots, and each sweep can run beside
+// another phase's chains instead of behind them (analysis_body).
+__device__ __forceinline__ v4f_ sq_diff4(const v4f_ hi, const v4f_ lo) {
+  v4f_ r;
+  r.x = hi.x * hi.x - lo.x * lo.x;
+  r.y = hi.y * hi.y - lo.y * lo.y;
+  r.z = hi.z * hi.z - lo.z * lo.z;
+  r.w = hi.w * hi.w - lo.w * lo.w;
+  return r;
+}
+__device__ __forceinline__ v4f_ sq_rev4(const v4f_ v) {  // squares, last component first (a sweep that walks DOWN x_lp)
+  v4f_ r;
+  r.x = v.w * v.w;
+  r.y = v.z * v.z;
+  r.z = v.y * v.y;
+  r.w = v.x * v.x;
+  return r;
+}
+// Syy of the fine find_best_pitch: step i adds x_lp[i+480]^2 - x_lp[i]^2; D[-1..295] receives what sweep_syy_fine_row leaves
+__device__ __forceinline__ void sweep_syy_fine_row_x(const float *xlp, float *D, float syy0, int l16) {
+  D[-1] = syy0;
+  float s = syy0;
+  ldsfw d = (ldsfw)D;
+  ldsf x = to_lds(xlp) + 4 * l16;
+  v4f_ a = sq_diff4(lds_read16(x + 480), lds_read16(x));
+  v4f_ hi = lds_read16(x + 64 + 480), lo = lds_read16(x + 64);
+#pragma unroll 1
+  for (int j = 0; j < 320; j += 64) {  // 296 steps: four whole blocks and 40 steps of a fifth
+    if (j < 256) {
+      SyyRowSteps<0>::run(s, a, d + j, true);
+    } else {  // steps 256 .. 295: ten of the sixteen groups
+      v4f_ o;
+#define SYY_G(K)                                              \
+      s = fmaxf(1.f, s + row_bcast<K>(a.x)); o.x = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.y)); o.y = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.z)); o.z = s;         \
+      s = fmaxf(1.f, s + row_bcast<K>(a.w)); o.w = s;         \
+      *(LDS_AS v4f_ *)(d + j + 4 * K) = o;
+      SYY_G(0) SYY_G(1) SYY_G(2) SYY_G(3) SYY_G(4) SYY_G(5) SYY_G(6) SYY_G(7) SYY_G(8) SYY_G(9)
+#undef SYY_G
+    }
+    a = sq_diff4(hi, lo);  // the next block's increments from the samples requested a block ago; then the block after that
+    const int jn = j + 128 < 320 ? j + 128 : 256;
+    hi = lds_read16(x + jn + 480);
+    lo = lds_read16(x + jn);
+  }
+}
+// yy_lookup of remove_doubling: step m = 0..383 is yy = (yy + x_lp[383-m]^2) - x_lp[863-m]^2, the value after it is yy_lookup[m+1];
+// yyl1 = &yy_lookup[1] (16-byte aligned), yy_lookup[0] = xx.  The values are stored as they are: the reference's MAX32(0, yy)
+// (src/pitch.c:452-455) is applied by the reader.
+__device__ __forceinline__ void sweep_yy_lookup_row_x(const float *xlp, float *yyl1, float xx, int l16) {
+  yyl1[-1] = xx;
+  float s = xx;
+  ldsfw out = (ldsfw)yyl1;
+  ldsf xa = to_lds(xlp) + 380 - 4 * l16, xb = to_lds(xlp) + 860 - 4 * l16;  // the samples of steps 4k .. 4k+3, last step first
+  v4f_ a = sq_rev4(lds_read16(xa)), b = sq_rev4(lds_read16(xb));
+  v4f_ ra = lds_read16(xa - 64), rb = lds_read16(xb - 64);
+#pragma unroll 1
+  for (int j = 0; j < 384; j += 64) {
+    YyRowSteps<0>::run(s, a, b, out + j, true);
+    a = sq_rev4(ra);
+    b = sq_rev4(rb);
+    const int jn = j + 128 < 384 ? j + 128 : 320;
+    ra = lds_read16(xa - jn);
+    rb = lds_read16(xb - jn);
+  }
+}
 __device__ __forceinline__ float pitch_gain(float xy, float xx, float yy) {  // src/pitch.c:416-419
   return (float)(xy / sqrt((double)(1 + xx * yy)));
 }
@@ -676,13 +747,21 @@ struct AnalysisLds {
 // a workgroup (grid = ceil(n_streams / SPW)).
 // `ring0` = physical ring position of pitch_buf[0] (src/denoise.c:359-360 shift = ring rotation).
 //
-// Narrow phases.  Three stretches of the pitch analysis are serial chains that occupy 1, 12 and 2
-// lanes of a wave for 148, 480 and 384 steps (coarse running energy; fine cross-correlations + start
-// energies; fine running energy + yy_lookup) -- a quarter of the kernel's instructions for a few
-// percent of its arithmetic.  A one-lane instruction costs the issue slot of a 64-lane one, so the
-// workgroup's waves meet at a barrier and wave 0 runs those chains for ALL SPW streams side by side
-// (disjoint lane groups, each lane pointing into its own stream's arena) while the other waves wait
-// without issuing anything.  Every chain is still one lane's serial sum in the reference order.
+// Narrow phases.  Stretches of the pitch analysis are serial chains that occupy 1, 12, 2 and 31 lanes of a
+// wave for 148, 480, 384 and 480 steps (coarse running energy; fine cross-correlations + start
+// energies; fine running energy + yy_lookup; the candidate dots of remove_doubling) -- a third of the
+// kernel's instructions for a few percent of its arithmetic.  A one-lane instruction costs the issue slot
+// of a 64-lane one, so the workgroup's waves meet at a barrier and ONE wave runs such a chain for all SPW
+// streams side by side (disjoint lane groups, each pointing into its own stream's arena; two waves with two
+// streams each for the 31-lane pass) while the others wait without issuing anything.  Every chain is still
+// one lane's serial sum in the reference order.  Between two barriers several of these phases run on
+// different waves at once, whenever their operands allow it:
+//   barrier | coarse running energy (nw1)                                                | barrier
+//   barrier | fine cross-correlations + <x, x> (nw2)  ||  start energy, then fine Syy (nw3a) | barrier
+//   barrier | candidate dots (nw1: streams 0, 1; nw3b: streams 2, 3)  ||  yy_lookup (nw2)    | barrier
+// (round 4, first form: the running energies ran in a phase of their own behind the fine chains, from squares and
+//  increments that every wave staged in LDS first, and each wave ran its own 31 candidate dots: 0.900 -> 0.854 ms at
+//  65,536 streams, profiles/r4_k1_phases.txt)
 // ---------------------------------------------------------------------------------------------
 #define K1_SPW 4       // streams (= waves) per workgroup of the inference kernels: 12 fine-search lanes x 4 <= 64
 #define SCR_MAIL 2328  // [8] mailbox of the stream inside its own arena: values handed between a stream's wave and wave 0
@@ -691,6 +770,7 @@ struct AnalysisLds {
 #define MAIL_BP1 2
 #define MAIL_XX 3      //   <x, x> of remove_doubling
 #define MAIL_SYY0F 4   //   start energy of the fine find_best_pitch
+#define MAIL_T0 5      //   remove_doubling's T0 (int bits), for the wave that runs this stream's candidate dots
 // K1_STOP(k): instrumented build only -- the whole workgroup leaves the kernel at stop point k (tools/k1_prefix.sh runs the
 // kernel once per stop point under the PMC counters: the differences are each section's LDS cycles, bank conflicts, VALU
 // instructions and time).  Stop points sit where all waves of a workgroup pass together.
@@ -705,18 +785,17 @@ template <bool TRAIN, int SPW>
 __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTablesDev &tb, int slot_arg, int parity,
                                               const RnTrainArgs &tr, int listed_row = -1) {
   const int slot = slot_arg & 255;
-  const int k1_stop = RN_INSTRUMENT ? (slot_arg >> 16) : 0;
+  const int k1_stop = RN_INSTRUMENT ? ((slot_arg >> 16) & 31) : 0;
   (void)k1_stop;
   // Which wave of the workgroup runs which narrow phase (see below).  Bit 9 of the slot argument: the four phases go to four
   // DIFFERENT waves, rotated from workgroup to workgroup by a hash of the block number -- the extra work is then spread over
   // the waves (and so over the SIMDs: a workgroup's waves sit on different SIMDs) instead of making wave 0 the straggler of
   // every workgroup, and the two running-energy sweeps of phase 3 advance side by side.  Clear: everything on wave 0 (round 3).
-  const bool spread = SPW > 1 && (slot_arg & 512);
-  const bool xrow = !(slot_arg & 1024);
+  const bool spread = SPW > 1;                            // (round 4 measured it against everything-on-wave-0 in one kernel: 4 %; that
+                                                          //  form now lives only in the one-stream workgroups, where wave 0 is the stream)
+  const bool xrow = !(slot_arg & 1024);                   // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2)
   const int narrow_prio = (slot_arg & 4096) ? 1 : 3;      // bit 12 (A/B runs): the narrow-phase waves keep the kernel's priority
-  const bool narrow_timing_only = slot_arg & 2048;        // bit 11 (timing experiments ONLY, wrong results): phase 3 skipped
-  const bool sweep_no_stores = slot_arg & 8192;           // bit 13 (timing experiments ONLY, wrong results): phase 3 without its LDS stores
-  const bool fine_deep = !(slot_arg & 16384);             // bit 14 (A/B runs): the fine-search chains fetch one block ahead, not two  // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2) instead
+  const bool fine_deep = !(slot_arg & 16384);             // bit 14 (A/B runs): the fine-search chains fetch one block ahead, not two
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -944,12 +1023,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   K1_STOP(8);
   WG_SYNC();
   if (spread) {
-    // narrow phase 2, spread.  Wave nw2: one ROW of 16 lanes per stream -- lanes 0..9 of the row the fine lags, lane 10 xx =
+    // narrow phase 2.  Wave nw2: one ROW of 16 lanes per stream -- lanes 0..9 of the row the fine lags, lane 10 xx =
     // <x, x> of remove_doubling, the rest idle along on <x, x> -- so that the chains of a row share x and take it from the
     // row's registers (chain_dot16_xrow), and every y operand is an aligned 8-byte read from x_lp or its shifted copy: a
     // third of the LDS cycles of the 12-lanes-per-stream form below, whose 4-byte reads at 24 unrelated offsets per access
     // group were mostly bank conflicts.  Wave nw3a, at the same time on another SIMD: the start energy 1 + sum x_lp[j]^2
-    // of the fine find_best_pitch of every stream, one lane each -- the value its own sweep of phase 3 starts from.
+    // of the fine find_best_pitch of every stream, one lane each, and from it the running energy Syy of the fine search,
+    // one row per stream (sweep_syy_fine_row_x: its increments are formed on the way, nothing of it waits for nw2's chains).
     if (wave == nw2) {
       if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
       const int gq = lane >> 4, r = lane & 15;  // (SPW == 4 rows)
@@ -969,62 +1049,35 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         float *ag = arenas[lane].a;
         ag[SCR_MAIL + MAIL_SYY0F] = chain_sq8(to_lds(ag + SCR_XLP), 480, 1.f);
       }
+      RN_WSYNC();
+      {  // (every lane takes part: the rows' DPP operands come from the other lanes' registers)
+        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+        sweep_syy_fine_row_x(a + SCR_XLP, a + SCR_D, a[SCR_MAIL + MAIL_SYY0F], lane & 15);
+      }
       __builtin_amdgcn_s_setprio(1);
     }
-    // every wave: the operands of the two running-energy sweeps of its own stream, over the shifted copy (dead now)
-    __syncthreads();
-    K1_STOP(17);  // (tools/k1_prefix.sh NARROW=1: narrow phase 2 ends here)
-    energy_sweeps_prepare(xlp, rsq, Dsyy, scr + SCR_ZERO, lane);
-  } else if (wave == 0) {
-    if (SPW > 1) __builtin_amdgcn_s_setprio(3);
-    // narrow phase 2: 12 lanes per stream -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
-    // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch
+  } else {
+    // one-stream workgroups: narrow phase 2 on 12 lanes -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
+    // lane 11 the start energy 1 + sum x_lp[j]^2 of the fine find_best_pitch -- then phase 3 on two: the fine running
+    // energy and yy_lookup
     {
-      // (two streams per 32-lane LDS access group: the per-lane-offset reads of a group then collide among 2 arenas' clusters
-      //  instead of 3; lanes 24..31 and 56..63 idle)
-      const int l5 = lane & 31, gq = 2 * (lane >> 5) + (l5 >= 12 ? 1 : 0), r = l5 - 12 * (l5 >= 12 ? 1 : 0);
-      const bool on = gq < SPW && l5 < 24;
-      const int gi = on ? gq : 0;
-      float *xlp_g = arenas[gi].a + SCR_XLP, *xc_g = arenas[gi].a + SCR_XC, *mail_g = arenas[gi].a + SCR_MAIL;
-      const int b0 = __float_as_int(mail_g[MAIL_BP0]), b1 = __float_as_int(mail_g[MAIL_BP1]);
+      const int r = lane;
+      const bool on = lane < 12;
+      const int b0 = __float_as_int(mail[MAIL_BP0]), b1 = __float_as_int(mail[MAIL_BP1]);
       const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
       const bool lag = on && r < 10 && c >= 0 && c < 294;
       float sum = 0;
       if (lag || (on && r >= 10))
-        sum = chain_dot8(to_lds(xlp_g + (r == 11 ? 0 : 384)), to_lds(xlp_g + (lag ? c : (r == 11 ? 0 : 384))), 480,
+        sum = chain_dot8(to_lds(xlp + (r == 11 ? 0 : 384)), to_lds(xlp + (lag ? c : (r == 11 ? 0 : 384))), 480,
                          r == 11 ? 1.f : 0.f);
-      if (lag) xc_g[c] = (-1 > sum) ? -1 : sum;
-      if (on && r == 10) mail_g[MAIL_XX] = sum;
-      if (on && r == 11) mail_g[MAIL_SYY0F] = sum;
+      if (lag) xc[c] = (-1 > sum) ? -1 : sum;
+      if (on && r == 10) mail[MAIL_XX] = sum;
+      if (on && r == 11) mail[MAIL_SYY0F] = sum;
     }
     RN_WSYNC();
-    CLK_TAP(6);  // fine xcorr (+ the two start energies) of the whole workgroup (wave 0's view)
-  }
-  if (spread) {
-    // narrow phase 3, spread: the fine running energy of every stream on one wave, yy_lookup of every stream on another
-    __syncthreads();
-    K1_STOP(18);  // (the sweeps' operands are in place)
-    if ((wave == nw3a || wave == nw3b) && !narrow_timing_only) {
-      if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
-      {  // (every lane takes part: the rows' DPP operands come from the other lanes' registers)
-        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
-        if (wave == nw3a) sweep_syy_fine_row(a + SCR_D, a[SCR_MAIL + MAIL_SYY0F], lane & 15);
-        else sweep_yy_lookup_row(a + SCR_SQ, a[SCR_MAIL + MAIL_XX], lane & 15, !sweep_no_stores);
-      }
-      __builtin_amdgcn_s_setprio(1);
-    }
-  } else if (wave == 0) {
-    // narrow phase 3: two lanes per stream -- the fine running energy and yy_lookup
-    {
-      const int gq = lane >> 1, role = lane & 1;
-      const bool on = gq < SPW;
-      const int gi = on ? gq : 0;
-      float *a = arenas[gi].a;
-      const float *mail_g = arenas[gi].a + SCR_MAIL;
-      energy_sweeps_run(a + SCR_SQ, a + SCR_D, a + SCR_ZERO, mail_g[MAIL_SYY0F], mail_g[MAIL_XX], role, on);
-    }
-    CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps of the whole workgroup (wave 0's view)
-    if (SPW > 1) __builtin_amdgcn_s_setprio(1);
+    CLK_TAP(6);  // fine xcorr (+ the two start energies)
+    energy_sweeps_run(scr + SCR_SQ, scr + SCR_D, scr + SCR_ZERO, mail[MAIL_SYY0F], mail[MAIL_XX], lane & 1, lane < 2);
+    CLK_TAP(9);  // fine-search Syy + yy_lookup sweeps
   }
   WG_SYNC();
   K1_STOP(9);
@@ -1056,18 +1109,26 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const float prev_gain = g.last_gain[s];
     if (T0 >= maxperiod) T0 = maxperiod - 1;
     int T = T0;
-    RN_WSYNC();  // the fine xcorr and the fine Syy are dead from here on
-    // yy_lookup = max(0, swept values) (src/pitch.c:452-455) moves out of the squares array into the dead areas, and the
-    // squares array becomes xs[i] = x_lp[i + 1]: every dot product below can then fetch its y operand 8 bytes at a time
-    // from an 8-byte aligned address, whatever the parity of its offset
-    float *yyl = scr + SCR_YYL, *xs = scr + SCR_XS;
-    {
+    // yy_lookup[i] lives at scr[SCR_YYL - 1 + i], over the dead Syy / fine xcorr areas, UNCLAMPED: the readers below apply the
+    // reference's MAX32(0, yy) (src/pitch.c:452-455; yy_lookup[0] = xx, a sum of squares, is its own maximum with 0)
+    float *yyl = scr + SCR_YYL - 1;
+    if (spread) {
+      // x_lp's shifted copy is still in place (nothing was staged over it), and yy_lookup is swept NOW, beside the candidate
+      // dots, by a third wave -- straight into its final place, which is free once every stream of the workgroup is through
+      // its fine selection: that, and T0 for the wave that runs this stream's dots, is what the barrier stands for
+      if (lane == 0) mail[MAIL_T0] = __int_as_float(T0);
+      __syncthreads();
+    } else {
+      RN_WSYNC();  // the fine xcorr and the fine Syy are dead from here on
+      // one-stream workgroups: yy_lookup moves out of the squares array into the dead areas, and the squares array becomes
+      // xs[i] = x_lp[i + 1]: every dot product below can then fetch its y operand 8 bytes at a time from an 8-byte aligned
+      // address, whatever the parity of its offset
+      float *xs = scr + SCR_XS;
       float t[7], u[14];
 #pragma unroll
       for (int k = 0; k < 7; k++) {  // 385 = 6.02 x 64
         const int i0 = lane + WAVE * k, i = i0 <= 384 ? i0 : 384;
-        const float v = rsq[479 + i];
-        t[k] = i ? fmaxf(0.f, v) : v;  // yy_lookup[0] = xx is stored as it is (src/pitch.c:450), MAX32(0, yy) for the others
+        t[k] = rsq[479 + i];
       }
 #pragma unroll
       for (int k = 0; k < 14; k++) {
@@ -1085,11 +1146,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         const int i0 = lane + WAVE * k;
         if (i0 < 863) xs[i0] = u[k];
       }
+      RN_WSYNC();
     }
-    RN_WSYNC();
     K1_STOP(11);
-    // Every dot product the decision loop can ask for, in ONE pass of 480-step chains on the first 32 lanes (each chain
-    // is an independent serial sum, so computing it speculatively changes no bit):
+    // Every dot product the decision loop can ask for, in ONE pass of 480-step chains on 31 lanes (each chain is an
+    // independent serial sum, so computing it speculatively changes no bit):
     //   lane 1: xy(T0);  lanes 2..29: (k, T1 / T1b), k = 2..15 (pitch.c:462-483);  lanes 30, 31: the -1 / +1 neighbours of T0,
     //   which the final 3-point refinement (pitch.c:511-512) needs when no shorter period wins.
     //   (xx, the chain at offset 0, came out of energy_sweeps)
@@ -1097,31 +1158,52 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // all 30 neighbour chains speculatively on lanes 32..61: 59 lanes with unrelated offsets collide on the LDS banks --
     // 2,860 LDS cycles per frame, half of them conflicts, a third of the whole kernel's; 31 lanes fill one 32-lane access
     // group and leave the other empty.)
-    {
+    // Paired (workgroups of four streams): the pass costs the issue slots of 64 lanes whether 31 or 62 of them carry a chain,
+    // so two waves of the workgroup run it for two streams each -- lanes 0..31 one stream, 32..63 the other, each half an LDS
+    // access group of its own reading its own arena -- and the other two wait at the barrier without issuing anything: half
+    // the instructions per frame for the kernel's largest chain pass (every lane's chain is what it was).
+    auto candidate_dots = [&](float *ag, int T0g, int l) {
       int off = -1;
-      if (lane == 1) off = T0;
-      else if (lane >= 2 && lane < 30) {
-        int k = 2 + ((lane - 2) >> 1);
-        int T1 = (2 * T0 + k) / (2 * k), T1b;
-        if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
-        else T1b = (2 * sc[k] * T0 + k) / (2 * k);
-        off = ((lane - 2) & 1) ? T1b : T1;
-      } else if (lane == 30 || lane == 31) {
-        off = T0 + ((lane & 1) ? 1 : -1);
+      if (l == 1) off = T0g;
+      else if (l >= 2 && l < 30) {
+        int k = 2 + ((l - 2) >> 1);
+        int T1 = (2 * T0g + k) / (2 * k), T1b;
+        if (k == 2) T1b = (T1 + T0g > maxperiod) ? T0g : T0g + T1;
+        else T1b = (2 * sc[k] * T0g + k) / (2 * k);
+        off = ((l - 2) & 1) ? T1b : T1;
+      } else if (l == 30 || l == 31) {
+        off = T0g + ((l & 1) ? 1 : -1);
         if (off < 0) off = 0;
       }
       // every lane runs a chain (chain_dot16_xrow takes x from the registers of the other lanes of its row); the lanes without
       // an offset of their own run <x, x>, all of them on the same addresses (a broadcast, not a bank conflict), and drop it
       const int a = maxperiod - (off >= 0 ? off : 0);  // y = x_lp + a
-      ldsf ya = to_lds(scr + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a));
-      const float d = xrow ? chain_dot16_xrow<false>(to_lds(x), ya, N, lane) : (off >= 0 ? chain_dot8_y2(to_lds(x), ya, N) : 0.f);
-      if (off >= 0) dots[lane] = d;
+      ldsf xg = to_lds(ag + SCR_XLP + maxperiod), ya = to_lds(ag + ((a & 1) ? SCR_XS + (a - 1) : SCR_XLP + a));
+      const float d = xrow ? chain_dot16_xrow<false>(xg, ya, N, lane) : (off >= 0 ? chain_dot8_y2(xg, ya, N) : 0.f);
+      if (off >= 0) ag[SCR_DOTS + l] = d;
+    };
+    if (spread) {
+      if (wave == nw1 || wave == nw3b) {
+        if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
+        float *ag = arenas[(wave == nw1 ? 0 : 2) + (lane >> 5)].a;
+        const int T0g = __float_as_int(ag[SCR_MAIL + MAIL_T0]);
+        candidate_dots(ag, T0g, lane & 31);
+        __builtin_amdgcn_s_setprio(1);
+      } else if (wave == nw2) {  // yy_lookup of every stream, one row each (every lane takes part: DPP operands)
+        if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
+        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+        sweep_yy_lookup_row_x(a + SCR_XLP, a + SCR_YYL, a[SCR_MAIL + MAIL_XX], lane & 15);
+        __builtin_amdgcn_s_setprio(1);
+      }
+      __syncthreads();
+    } else {
+      candidate_dots(scr, T0, lane);
     }
     RN_WSYNC();
     float xy = dots[1];
     CLK_TAP(8);  // 59 candidate dot products of remove_doubling
     K1_STOP(12);
-    float yy = yyl[T0];
+    float yy = fmaxf(0.f, yyl[T0]);
     float best_xy = xy, best_yy = yy;
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
     const float g0 = pitch_gain(xy, xx, yy);
@@ -1139,7 +1221,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       else T1b = (2 * sc[k] * T0 + k) / (2 * k);
       float xy1 = dots[2 + 2 * (k - 2)], xy2 = dots[3 + 2 * (k - 2)];
       xy1 = .5f * (xy1 + xy2);
-      const float yy1 = .5f * (yyl[T1] + yyl[T1b]);
+      const float yy1 = .5f * (fmaxf(0.f, yyl[T1]) + fmaxf(0.f, yyl[T1b]));
       const float g1 = pitch_gain(xy1, xx, yy1);
       float cont;
       int dT = T1 - prev_period;
@@ -1387,7 +1469,15 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 // Hermitian-extended spectrum passes once through LDS (natural order in, 15 consecutive bins out per lane) and the time
 // samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(WAVE)
+#ifndef RN_K3_W4
+#define RN_K3_W4 0
+#endif
+#if RN_K3_W4
+#define K3_ATTR __attribute__((amdgpu_waves_per_eu(RN_K3_W4 >= 3 ? 5 : 4, RN_K3_W4 >= 3 ? 5 : 4)))
+#else
+#define K3_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(WAVE) K3_ATTR
 rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
   // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
   // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
@@ -1439,8 +1529,8 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     const int p = WAVE * b + pos;
     const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
     const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
-    wv[b] = tb.half_window[n];
-    smv[b] = lo ? sm[n] : 0.f;
+    if (!RN_K3_W4) wv[b] = tb.half_window[n];
+    if (RN_K3_W4 < 2) smv[b] = lo ? sm[n] : 0.f;
   }
 
 // src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
@@ -1522,6 +1612,18 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     }
   }
   regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));
+  if (RN_K3_W4) {  // (the window values come from L1 / L2: requested only now, they do not sit in 15 registers through the transform)
+    int pos_late = pos;
+    asm volatile("" : "+v"(pos_late), "+v"(yr[14]));  // (an index the scheduler cannot have before the transform is done)
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+      const int p = WAVE * b + pos_late;
+      const bool lo = p == 0 || p > RN_FRAME_SIZE;
+      const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
+      wv[b] = tb.half_window[n];
+      if (RN_K3_W4 >= 2) smv[b] = lo ? sm[n] : 0.f;
+    }
+  }
   // window + overlap-add (src/denoise.c:400-407), straight from the registers
   float *o = listed ? rows.io + (size_t)s * RN_ROW_IO + RN_FRAME_SIZE + 4 : out + (size_t)s * RN_FRAME_SIZE;
 #pragma unroll
@@ -1569,13 +1671,11 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
     static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
     static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
-    // narrow phases spread over the waves of a workgroup (analysis_body); RNNOISE_AMD_K1_SPREAD=0: all on wave 0 (A/B runs)
-    static const int spread = [] { const char *e = getenv("RNNOISE_AMD_K1_SPREAD"); return (e && atoi(e) == 0) ? 0 : 512; }();
     static const int noxrow = [] {
-      const char *e = getenv("RNNOISE_AMD_K1_XROW"), *x = getenv("RNNOISE_AMD_K1_EXPERIMENT");  // (experiment: 2048 / 4096 / both, see analysis_body)
-      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (2048 | 4096 | 8192 | 16384)) : 0);
+      const char *e = getenv("RNNOISE_AMD_K1_XROW"), *x = getenv("RNNOISE_AMD_K1_EXPERIMENT");  // (A/B bits 12, 14: see analysis_body)
+      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (4096 | 16384)) : 0);
     }();
-    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | spread | noxrow, parity);
+    RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | noxrow, parity);
   }
   return hipGetLastError();
 }

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from valu_mix import COST, classify  # noqa: E402
 
 NAMES = ["window X", "FFT X", "store X + Ex", "downsample+FIR", "y4/Z + coarse pass 1", "coarse pass 2", "narrow 1 + coarse select",
-         "sweep operands", "narrow 2+3", "fine select", "doubling prep", "doubling dots", "decide", "window P + loads",
+         "shifted copy", "narrow 2+3", "fine select", "doubling prep", "doubling dots", "decide", "window P + loads",
          "FFT P", "store P + Ep + Exp", "features (rest)"]
 
 # trip counts of the loops that survive unrolling, by section and order of appearance (source loop bounds; data-dependent
@@ -27,17 +27,16 @@ NAMES = ["window X", "FFT X", "store X + Ex", "downsample+FIR", "y4/Z + coarse p
 LOOP_TRIPS = {
     "store X + Ex": [2, 7],                  # band_sums: 8 slots per trip for the chains that long, then one slot per trip
     "y4/Z + coarse pass 1": [15],            # chain_dot8_x3: 240 / 8 steps, unrolled by 2
-    "narrow 1 + coarse select": [3, 4, 4, 4],   # fbp_sweep_row: 3 blocks of 64 steps; best_pitch_select: ~4 passing lags per batch of 64
-    "narrow 2 (fine chains)": [10, 5, 14, 30, 30],  # chain_dot16_xrow<deep>: 10 x 48 steps; xc clear; shifted copy; the 1-block variant; chain_sq8
-    "sweep operands (spread)": [14, 5, 1],
-    "narrow 3 (sweeps)": [5, 6],             # 5 / 6 blocks of 64 steps
+    "narrow 1 + coarse select": [3],         # fbp_sweep_row: 3 blocks of 64 steps (best_pitch_select's loops: counted once)
+    "narrow 2+3": [30, 0, 10],               # chain_sq8 (16 steps per trip); the one-block-ahead chain (A/B only); chain_dot16_xrow<deep>: 10 x 48
+                                             # steps.  sweep_syy_fine_row_x's 5 blocks close on a branch the rule below does not see: counted once
     "fine select": [4, 4, 4, 4, 4],
-    "doubling dots": [30, 1],                # chain_dot16_xrow 480 / 16; the per-lane-x variant is not taken
+    "doubling dots": [6, 30, 0],             # sweep_yy_lookup_row_x: 6 blocks of 64 steps; chain_dot16_xrow 480 / 16; the per-lane-x variant is not taken
     "decide": [0],                           # (the second two-lane pass runs only when a shorter period wins)
     "store P + Ep + Exp": [2, 7],
 }
-# sections that one wave runs for the K1_SPW = 4 streams of its workgroup: per-wave share of their loops
-SHARED = {"narrow 1 + coarse select": [0.25, 1, 1, 1], "narrow 2 (fine chains)": [0.25, 1, 1, 0, 0.25], "narrow 3 (sweeps)": [0.25, 0.25]}
+# sections that one or two waves run for the K1_SPW = 4 streams of their workgroup: per-wave share of their loops
+SHARED = {"narrow 1 + coarse select": [0.25], "narrow 2+3": [0.25, 0.25, 0.25], "doubling dots": [0.25, 0.5, 1]}
 
 
 def compile_asm(flags, keep):
@@ -76,7 +75,7 @@ def kind_of(mn):
 
 def analyse(lines, with_trips=True):
     # split into sections at the marks
-    # a section = the code in front of a mark, named after the mark's number (marks 17 and 18 sit inside the narrow phases)
+    # a section = the code in front of a mark, named after the mark's number
     sections, marks = [[]], []
     for ln in lines:
         m = re.match(r"\s*; K1MARK (\d+)", ln)
@@ -85,11 +84,10 @@ def analyse(lines, with_trips=True):
             sections.append([])
             continue
         sections[-1].append(ln)
-    extra = {17: "narrow 2 (fine chains)", 18: "sweep operands (spread)", 9: "narrow 3 (sweeps)"}
     rows = []
     for si, sec in enumerate(sections):
         mk = marks[si] if si < len(marks) else None
-        name = (extra.get(mk) if (mk in extra and 17 in marks) else None) or (NAMES[mk - 1] if mk and mk - 1 < len(NAMES) else NAMES[-1])
+        name = NAMES[mk - 1] if mk and mk - 1 < len(NAMES) else NAMES[-1]
         # instruction list with label positions
         labels, insts, headers = {}, [], set()
         for ln in sec:

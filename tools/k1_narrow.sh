@@ -1,10 +1,11 @@
 #!/bin/bash
-# the narrow phases of rn_analysis_kernel in detail: stop points 8 (before phase 2), 17 (after phase 2), 18 (sweep operands ready), 9 (after phase 3)
+# the narrow phases of rn_analysis_kernel in detail: stop points 6 / 7 (around phase 1 + coarse selection), 8 / 9 (around phase 2: fine chains beside
+# the fine running energy), 10 (fine selection), 11 / 12 (around the paired candidate dots beside the yy_lookup sweep)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-k1_narrow}
 mkdir -p "$O"; export TMPDIR=/tmp; cd /tmp
-for k in 7 8 17 18 9; do
+for k in 6 7 8 9 10 11 12; do
   rm -rf "$O/p"
   RNNOISE_AMD_K1_STOP=$k rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES \
       --output-format csv -d "$O/p" -- python "$R/tools/k1_prefix.py" 65536 4 > "$O/run_$k.log" 2>&1

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-k1_prefix}
 N=${2:-65536}
 mkdir -p "$O"; export TMPDIR=/tmp; cd /tmp
-NAMES=(whole "window X" "FFT X" "store X + Ex" "downsample+FIR" "y4/Z + coarse pass 1" "coarse pass 2" "narrow 1 + coarse select" "sweep operands" "narrow 2+3" "fine select" "doubling prep" "doubling dots" "decide" "window P + loads" "FFT P" "store P + Ep + Exp" )
+NAMES=(whole "window X" "FFT X" "store X + Ex" "downsample+FIR" "y4/Z + coarse pass 1" "coarse pass 2" "narrow 1 + coarse select" "shifted copy" "narrow 2+3" "fine select" "doubling prep" "doubling dots" "decide" "window P + loads" "FFT P" "store P + Ep + Exp" )
 echo "stop,section,ms,waves,valu_per_wave,salu_per_wave,lds_inst_per_wave,lds_cyc_per_wave,conflict_cyc_per_wave,wave_cycles,wait_lds_pct" > "$O/k1_prefix.csv"
 for k in 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 0; do
   rm -rf "$O/p"
