@@ -39,6 +39,10 @@ __device__ __constant__ int c_second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 
 // one the compiler emits flat_load, which the LDS serves at a fraction of a ds_read's rate (round 2's doubling dots and
 // fine-search chains ran on flat loads: 9-12 LDS cycles per instruction, profiles/r3_k1_sections_before.txt).
 #define LDS_AS __attribute__((address_space(3)))
+// ... and global tables.  A pointer that went through an empty asm (the "opaque copies" below) is a generic one to the compiler:
+// loads through it become flat_load, which counts on lgkmcnt as well as vmcnt, so every later wait for an LDS result also
+// waits for the table values.  The tables are global memory; saying so keeps them global_load.
+#define GLOBAL_AS __attribute__((address_space(1)))
 typedef const LDS_AS float *ldsf;
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -71,9 +75,10 @@ __device__ __forceinline__ float row_bcast(float v) {  // lane K of each 16-lane
 template <int NARR, int NX, int NY>
 __device__ __forceinline__ void band_products(float *Q, const float (&xr)[NX], const float (&xi)[NX], const float (&yr)[NY],
                                               const float (&yi)[NY], const RnTablesDev &tb, int pos, int lane) {
-  const uint32_t *band_q = tb.band_q;  // opaque copies: re-read from L1 at every call rather than kept across the pitch stage
-  const float *band_frac = tb.band_frac;
-  const uint16_t *band_pad = tb.band_pad;
+  // opaque copies: re-read from L1 at every call rather than kept across the pitch stage
+  const GLOBAL_AS uint32_t *band_q = (const GLOBAL_AS uint32_t *)tb.band_q;
+  const GLOBAL_AS float *band_frac = (const GLOBAL_AS float *)tb.band_frac;
+  const GLOBAL_AS uint16_t *band_pad = (const GLOBAL_AS uint16_t *)tb.band_pad;
   asm volatile("" : "+s"(band_q), "+s"(band_frac), "+s"(band_pad));
   {  // the pad floats of every accumulator (RnTablesDev::band_pad): +0.0f
     const int ps = band_pad[lane];
@@ -548,6 +553,37 @@ __device__ __forceinline__ float chain_sq8(ldsf y, int n, float s0) {
   return s;
 }
 
+// chain_sq8 for a pass in which every lane of the wave takes part, one ROW of 16 lanes per chain: lane k of the row squares
+// y[i + k] (one 4-byte read and one multiply per 16 steps) and step k adds lane k's square as a DPP operand
+// (v_add_f32_dpp row_newbcast:k) -- 18 instructions per 16 steps instead of 36, on a wave that runs alone between two
+// barriers and issues one instruction per ~5 cycles whatever it is.  Same squares, same order of adds; every lane of the
+// row ends with the chain's value.  n a multiple of 16.
+template <int K>
+struct SqRowSteps {
+  static __device__ __forceinline__ void run(float &s, float q) {
+    s = s + row_bcast<K>(q);
+    SqRowSteps<K + 1>::run(s, q);
+  }
+};
+template <>
+struct SqRowSteps<16> {
+  static __device__ __forceinline__ void run(float &, float) {}
+};
+__device__ __forceinline__ float chain_sq_row(ldsf y, int n, float s0, int l16) {
+  float s = s0;
+  ldsf yl = y + l16;
+  float v = yl[0], vn = yl[16];
+#pragma unroll 1
+  for (int i = 0; i < n; i += 16) {
+    float q = v * v;
+    OPAQUE(q);
+    v = vn;
+    vn = yl[i + 32 < n ? i + 32 : i];  // two blocks ahead (the block is 16 dependent adds long)
+    SqRowSteps<0>::run(s, q);
+  }
+  return s;
+}
+
 // chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
 // For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
 // dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
@@ -838,7 +874,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // (`start` wave-uniform.  All 30 loads are in flight together; the ring position wraps at most once inside a window, which
   // an unsigned minimum resolves -- a - SIZE is huge when a < SIZE -- and which half of the window a sample is in is known
   // at compile time for every t but one)
-  auto window_to_regs = [&](float (&ar)[15], float (&ai)[15], int start, const float *hw) {
+  auto window_to_regs = [&](float (&ar)[15], float (&ai)[15], int start, const float *hw_) {
+    const GLOBAL_AS float *hw = (const GLOBAL_AS float *)hw_;
     int p0 = ring0 + start;
     p0 = (p0 >= RN_RING_SIZE) ? p0 - RN_RING_SIZE : p0;
     const unsigned pl = (unsigned)p0 + (unsigned)lane;
@@ -1045,14 +1082,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       __builtin_amdgcn_s_setprio(1);
     } else if (wave == nw3a) {
       if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
-      if (lane < SPW) {
-        float *ag = arenas[lane].a;
-        ag[SCR_MAIL + MAIL_SYY0F] = chain_sq8(to_lds(ag + SCR_XLP), 480, 1.f);
-      }
-      RN_WSYNC();
       {  // (every lane takes part: the rows' DPP operands come from the other lanes' registers)
         float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
-        sweep_syy_fine_row_x(a + SCR_XLP, a + SCR_D, a[SCR_MAIL + MAIL_SYY0F], lane & 15);
+        const float syy0 = chain_sq_row(to_lds(a + SCR_XLP), 480, 1.f, lane & 15);
+        sweep_syy_fine_row_x(a + SCR_XLP, a + SCR_D, syy0, lane & 15);
       }
       __builtin_amdgcn_s_setprio(1);
     }
@@ -1469,15 +1502,11 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 // Hermitian-extended spectrum passes once through LDS (natural order in, 15 consecutive bins out per lane) and the time
 // samples come out in registers, lane l holding work-area positions 64*blk + p.  4.9 KB of LDS per wave.
 // ---------------------------------------------------------------------------------------------
-#ifndef RN_K3_W4
-#define RN_K3_W4 0
+// (5 waves per SIMD: the transform needs ~95 registers, and the operands of the overlap-add are requested behind it -- see below)
+#ifndef RN_K3_WAVES
+#define RN_K3_WAVES 5  // (A/B builds: -DRN_K3_WAVES=6 spills 12 registers)
 #endif
-#if RN_K3_W4
-#define K3_ATTR __attribute__((amdgpu_waves_per_eu(RN_K3_W4 >= 3 ? 5 : 4, RN_K3_W4 >= 3 ? 5 : 4)))
-#else
-#define K3_ATTR
-#endif
-extern "C" __global__ void __launch_bounds__(WAVE) K3_ATTR
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(RN_K3_WAVES, RN_K3_WAVES)))
 rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
   // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
   // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
@@ -1521,17 +1550,8 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   }
   // After the transform this lane holds y[p], p = 64*blk + pos, blk = 0..14; time sample n = (960 - p) % 960
   // (src/denoise.c:213-216).  n < 480: out[n] = 960*y*w[n] + synthesis_mem[n];  n >= 480: synthesis_mem[n - 480] =
-  // 960*y*w[959 - n] = 960*y*w[p - 1]  (src/denoise.c:400-407).  Operands of both are requested now.
+  // 960*y*w[959 - n] = 960*y*w[p - 1]  (src/denoise.c:400-407).
   float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
-  float smv[15], wv[15];
-#pragma unroll
-  for (int b = 0; b < 15; b++) {
-    const int p = WAVE * b + pos;
-    const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
-    const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
-    if (!RN_K3_W4) wv[b] = tb.half_window[n];
-    if (RN_K3_W4 < 2) smv[b] = lo ? sm[n] : 0.f;
-  }
 
 // src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
 #define BAND(j) ((int)(bq[j] >> 22))
@@ -1612,16 +1632,22 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
     }
   }
   regfft960<RN_FFT_XLANE>(yr, yi, lane, reinterpret_cast<const float2 *>(tb.fft_tw));
-  if (RN_K3_W4) {  // (the window values come from L1 / L2: requested only now, they do not sit in 15 registers through the transform)
+  // The operands of the overlap-add -- 15 window values (L1 / L2) and the lane's 7 or 8 synthesis_mem samples (HBM) -- are
+  // requested only NOW.  Requested with the other operands at the top they sat in 30 registers through the band stages and the
+  // transform: 142 VGPRs, three waves per SIMD, 0.29 ms at 65,536 streams; behind the transform the kernel needs 96, five
+  // waves fit, and four of them cover the fifth's wait for these loads: 0.237 ms (profiles/r4_k3_occupancy.txt).  The index
+  // goes through an empty asm together with a transform output so that the scheduler cannot hoist the loads back up.
+  float smv[15], wv[15];
+  {
     int pos_late = pos;
-    asm volatile("" : "+v"(pos_late), "+v"(yr[14]));  // (an index the scheduler cannot have before the transform is done)
+    asm volatile("" : "+v"(pos_late), "+v"(yr[14]));
 #pragma unroll
     for (int b = 0; b < 15; b++) {
       const int p = WAVE * b + pos_late;
-      const bool lo = p == 0 || p > RN_FRAME_SIZE;
+      const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
       const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
       wv[b] = tb.half_window[n];
-      if (RN_K3_W4 >= 2) smv[b] = lo ? sm[n] : 0.f;
+      smv[b] = lo ? sm[n] : 0.f;
     }
   }
   // window + overlap-add (src/denoise.c:400-407), straight from the registers

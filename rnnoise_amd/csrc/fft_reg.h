@@ -116,13 +116,22 @@ __device__ __forceinline__ void fft_radix4_xlane(float (&ar)[15], float (&ai)[15
 // In: a[blk] = scaled sample 15*fft_lam(lane) + fft_c(blk).  Out: a[blk] = bin 64*blk + fft_pos(lane).
 // ftw: RnTablesDev::fft_tw.  epi3i = twiddles[320].i, ya = twiddles[192], yb = twiddles[384] (kiss_fft.c:187,246-247).
 template <int VARIANT>
-__device__ __forceinline__ void regfft960(float (&ar)[15], float (&ai)[15], int lane, const float2 *__restrict__ ftw) {
-  const float2 t2 = ftw[RN_FTW_S2 * 64 + lane], t3 = ftw[RN_FTW_S3 * 64 + lane];
+__device__ __forceinline__ void regfft960(float (&ar)[15], float (&ai)[15], int lane, const float2 *__restrict__ ftw_) {
+  // the table is global memory whatever the compiler knows about the pointer's origin (a caller that hides it behind an empty
+  // asm would otherwise get flat_load, which counts on the LDS counter as well: every wait for an LDS result then also waits for
+  // the twiddles)
+  typedef float f2raw __attribute__((ext_vector_type(2)));
+  const __attribute__((address_space(1))) f2raw *ftw_g = (const __attribute__((address_space(1))) f2raw *)ftw_;
+  auto ftw = [&](int i) {
+    const f2raw v = ftw_g[i];
+    return make_float2(v.x, v.y);
+  };
+  const float2 t2 = ftw(RN_FTW_S2 * 64 + lane), t3 = ftw(RN_FTW_S3 * 64 + lane);
   fft_radix4_xlane<0, false, VARIANT>(ar, ai, lane, rcpx{1.f, 0.f});
   fft_radix4_xlane<2, true, VARIANT>(ar, ai, lane, rcpx{t2.x, t2.y});
   fft_radix4_xlane<4, true, VARIANT>(ar, ai, lane, rcpx{t3.x, t3.y});
   {  // radix 3, m = 64 (kiss_fft.c:201-225)
-    const float2 w1 = ftw[(RN_FTW_R3 + 0) * 64 + lane], w2 = ftw[(RN_FTW_R3 + 1) * 64 + lane];
+    const float2 w1 = ftw((RN_FTW_R3 + 0) * 64 + lane), w2 = ftw((RN_FTW_R3 + 1) * 64 + lane);
     const float epi3i = -0.86602540378443864676f;  // (float)sin(-2 pi / 3) = twiddles[5 * 64].i
 #pragma unroll
     for (int u = 0; u < 5; u++) {
@@ -148,8 +157,8 @@ __device__ __forceinline__ void regfft960(float (&ar)[15], float (&ai)[15], int 
     const float ybr = -0.80901699437494742410f, ybi = -0.58778525229247312917f;  // twiddles[384] = exp(-4 pi i / 5)
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const float2 w1 = ftw[(RN_FTW_R5 + 4 * t + 0) * 64 + lane], w2 = ftw[(RN_FTW_R5 + 4 * t + 1) * 64 + lane];
-      const float2 w3 = ftw[(RN_FTW_R5 + 4 * t + 2) * 64 + lane], w4 = ftw[(RN_FTW_R5 + 4 * t + 3) * 64 + lane];
+      const float2 w1 = ftw((RN_FTW_R5 + 4 * t + 0) * 64 + lane), w2 = ftw((RN_FTW_R5 + 4 * t + 1) * 64 + lane);
+      const float2 w3 = ftw((RN_FTW_R5 + 4 * t + 2) * 64 + lane), w4 = ftw((RN_FTW_R5 + 4 * t + 3) * 64 + lane);
       const float s0r = ar[t], s0i = ai[t];
       const float x1r = ar[t + 3], x1i = ai[t + 3], x2r = ar[t + 6], x2i = ai[t + 6];
       const float x3r = ar[t + 9], x3i = ai[t + 9], x4r = ar[t + 12], x4i = ai[t + 12];

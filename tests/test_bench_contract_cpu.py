@@ -134,3 +134,31 @@ def test_round3_bench_lines_carry_parity_and_the_new_rooflines():
         assert d["parity"]["bit_identical"] is True and d["parity"]["streams"] == 32, f
         if "roofline_lds" in d:
             assert 0 < d["roofline_lds"]["frac"] < 1 and 0 < d["roofline_valu"]["frac_f32_peak"] <= d["roofline_valu"]["frac"] < 1, f
+
+
+def test_round4_rooflines_are_measurements():
+    """round 4: the VALU / LDS rooflines of the bench line stand on measured inputs -- the K1 instruction mix is weighted by the
+    per-section instruction counts of the PMC passes (not by the static listing), the shader clock comes from GRBM_GUI_ACTIVE
+    over the kernel's duration (one figure, <= the 2.4 GHz the part can reach), and the committed r4 lines say which they used"""
+    mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+    k1 = mix["kernels"]["rn_analysis_kernel"]
+    assert k1["weighting"].startswith("dynamic") and len(k1["sections"]) == 17
+    assert sum(s["valu"] for s in k1["sections"]) == k1["valu_dynamic_per_wave"]
+    assert mix["cost"]["fast"] <= k1["mean_cycles"] <= mix["cost"]["trans"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_by_streams.json")))
+    for n, rec in pmc["by_streams"].items():
+        for name, r in rec.items():
+            if isinstance(r, dict) and "clock_ghz" in r:
+                assert 1.5 <= r["clock_ghz"] <= 2.4 or name != "rn_analysis_kernel", (n, name, r["clock_ghz"])
+    assert "clock_ghz" in pmc["by_streams"]["65536"]["rn_analysis_kernel"]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r4_bench_*.json")))
+    assert len(files) >= 8
+    for f in files:
+        d = json.loads(open(f).read())
+        _check_line(d, f)
+        assert d["parity"]["bit_identical"] is True, f
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r4_bench_65536.json")).read())
+    v = d["roofline_valu"]
+    assert v["clocks_per_inst_kind"] == "dynamic" and "GRBM_GUI_ACTIVE" in v["clock_source"] and 1.5 <= v["clock_ghz"] <= 2.4
+    assert d["roofline_lds"]["clock_ghz"] == v["clock_ghz"]
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] >= 1
