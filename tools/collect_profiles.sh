@@ -42,5 +42,12 @@ RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_4096" "$G" -- python
 RNNOISE_AMD_PIPE=9 python "$R/tools/pmc_collect.py" "$O/pmc_little_32768" "$G" -- python "$R/bench.py" --no-cpu-baseline --model little --streams 32768 --steps 4 --warmup 1 --repeats 2 > "$O/pmc_little_32768.csv" 2>&1
 bash "$R/tools/k1_prefix.sh" prof/k1_prefix 65536 > /dev/null 2>&1
 cp "$O/k1_prefix/k1_prefix.txt" "$O/k1_sections.txt"; cp "$O/k1_prefix/k1_prefix.csv" "$O/k1_sections.csv"
+# the narrow phases once more with the wave-cycle and wait counters (tools/k1_narrow.sh: stop points 6 .. 12)
+bash "$R/tools/k1_narrow.sh" prof/k1_narrow > /dev/null 2>&1
+{ echo "# rn_analysis_kernel narrow phases (tools/k1_narrow.sh, 65,536 streams): the kernel with its workgroups leaving at stop point k."
+  echo "# 6 -> 7: barrier | coarse running energy on one wave | barrier + coarse selection;  8 -> 9: barrier | fine chains || start energy + fine Syy | barrier;"
+  echo "# 9 -> 10: fine selection;  11 -> 12: candidate dots on two waves || yy_lookup | barrier   (11 = behind the barrier that posts T0)"
+  cat "$O/k1_narrow/narrow.txt"; } > "$O/k1_narrow.txt"
+rm -rf "$O/k1_narrow"
 rm -rf "$O"/pmc_65536 "$O"/pmc_4096 "$O"/pmc_little_32768 "$O"/trace "$O"/b.log "$O"/k1_prefix
 ls -la "$O"

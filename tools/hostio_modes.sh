@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, GPU call F: host-fed path experiments -- both copy directions at once under different SDMA settings of the runtime
+# host-fed path experiments (on the GPU box) -- both copy directions at once under different SDMA settings of the runtime
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-r4f}
