@@ -336,21 +336,23 @@ struct YyRowSteps<16> {
 };
 // the coarse running energy (fbp_sweep) the same way: syy[i] holds the increment of step i going in and Syy BEFORE step i coming
 // out, i < 148; three blocks of 64 (the 44 steps past the end run on whatever the dead area behind holds and land there)
+// (all 16 lanes of a row store the same values to the same address; storing from lane 0 only is not faster -- 0.830 against
+//  0.827 ms, profiles/r4_k1_phases.txt -- same-address writes of an access group cost nothing extra)
 template <int K>
 struct SyyBeforeRowSteps {
-  static __device__ __forceinline__ void run(float &s, const v4f_ &a, ldsfw out) {
+  static __device__ __forceinline__ void run(float &s, const v4f_ &a, ldsfw out, bool store) {
     v4f_ o;
     o.x = s; s = fmaxf(1.f, s + row_bcast<K>(a.x));
     o.y = s; s = fmaxf(1.f, s + row_bcast<K>(a.y));
     o.z = s; s = fmaxf(1.f, s + row_bcast<K>(a.z));
     o.w = s; s = fmaxf(1.f, s + row_bcast<K>(a.w));
-    *(LDS_AS v4f_ *)(out + 4 * K) = o;
-    SyyBeforeRowSteps<K + 1>::run(s, a, out);
+    if (store) *(LDS_AS v4f_ *)(out + 4 * K) = o;
+    SyyBeforeRowSteps<K + 1>::run(s, a, out, store);
   }
 };
 template <>
 struct SyyBeforeRowSteps<16> {
-  static __device__ __forceinline__ void run(float &, const v4f_ &, ldsfw) {}
+  static __device__ __forceinline__ void run(float &, const v4f_ &, ldsfw, bool) {}
 };
 __device__ __forceinline__ void fbp_sweep_row(float *syy, float Syy0, int l16) {
   float s = Syy0;
@@ -359,49 +361,8 @@ __device__ __forceinline__ void fbp_sweep_row(float *syy, float Syy0, int l16) {
 #pragma unroll 1
   for (int j = 0; j < 192; j += 64) {
     const v4f_ an = *(const LDS_AS v4f_ *)(d + (j + 64 < 192 ? j + 64 : j) + 4 * l16);
-    SyyBeforeRowSteps<0>::run(s, a, d + j);
+    SyyBeforeRowSteps<0>::run(s, a, d + j, true);
     a = an;
-  }
-}
-// D: [-1..295] of the row's stream (16-byte aligned at D[0]); every lane of the wave takes part, l16 = lane & 15
-__device__ __forceinline__ void sweep_syy_fine_row(float *D, float syy0, int l16) {
-  D[-1] = syy0;
-  float s = syy0;
-  ldsfw d = (ldsfw)D;
-  v4f_ a = *(const LDS_AS v4f_ *)(d + 4 * l16);
-#pragma unroll 1
-  for (int j = 0; j < 320; j += 64) {  // 296 steps: four whole blocks and 40 steps of a fifth
-    const v4f_ an = *(const LDS_AS v4f_ *)(d + (j + 64 < 320 ? j + 64 : j) + 4 * l16);  // (past 295: the xcorr area, read and never used)
-    if (j < 256) {
-      SyyRowSteps<0>::run(s, a, d + j, true);
-    } else {  // steps 256 .. 295: ten of the sixteen groups
-      v4f_ o;
-#define SYY_G(K)                                              \
-      s = fmaxf(1.f, s + row_bcast<K>(a.x)); o.x = s;         \
-      s = fmaxf(1.f, s + row_bcast<K>(a.y)); o.y = s;         \
-      s = fmaxf(1.f, s + row_bcast<K>(a.z)); o.z = s;         \
-      s = fmaxf(1.f, s + row_bcast<K>(a.w)); o.w = s;         \
-      *(LDS_AS v4f_ *)(d + j + 4 * K) = o;
-      SYY_G(0) SYY_G(1) SYY_G(2) SYY_G(3) SYY_G(4) SYY_G(5) SYY_G(6) SYY_G(7) SYY_G(8) SYY_G(9)
-#undef SYY_G
-    }
-    a = an;
-  }
-}
-// rsq: the 864 reversed squares of the row's stream (energy_sweeps_prepare); results as energy_sweeps_run leaves them
-__device__ __forceinline__ void sweep_yy_lookup_row(float *rsq, float xx, int l16, bool store = true) {
-  rsq[479] = xx;
-  float s = xx;
-  ldsfw pa = (ldsfw)rsq + 480, pb = (ldsfw)rsq;
-  v4f_ a = *(const LDS_AS v4f_ *)(pa + 4 * l16), b = *(const LDS_AS v4f_ *)(pb + 4 * l16);
-#pragma unroll 1
-  for (int j = 0; j < 384; j += 64) {
-    const int jn = j + 64 < 384 ? j + 64 : j;
-    const v4f_ an = *(const LDS_AS v4f_ *)(pa + jn + 4 * l16), bn = *(const LDS_AS v4f_ *)(pb + jn + 4 * l16);
-    YyRowSteps<0>::run(s, a, b, pa + j, store);
-    if (!store) asm volatile("" ::"v"(s));  // (timing experiment: keep the chain alive)
-    a = an;
-    b = bn;
   }
 }
 // The two sweeps WITHOUT prepared operand arrays (workgroups of several streams): the operands of a block of 64 steps are
@@ -426,7 +387,7 @@ __device__ __forceinline__ v4f_ sq_rev4(const v4f_ v) {  // squares, last compon
   r.w = v.x * v.x;
   return r;
 }
-// Syy of the fine find_best_pitch: step i adds x_lp[i+480]^2 - x_lp[i]^2; D[-1..295] receives what sweep_syy_fine_row leaves
+// Syy of the fine find_best_pitch: step i adds x_lp[i+480]^2 - x_lp[i]^2; D[-1..295] receives Syy after each step (Syy before lag i = D[i - 1])
 __device__ __forceinline__ void sweep_syy_fine_row_x(const float *xlp, float *D, float syy0, int l16) {
   D[-1] = syy0;
   float s = syy0;
@@ -1022,7 +983,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // slot it can use (a lone wave issues once per ~5 cycles whatever its priority; profiles/r3_valu_issue.txt) ahead of the
     // three waves of other workgroups on its SIMD, which have independent work for the remaining slots.
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
-    if (spread) {  // one row of 16 lanes per stream (see sweep_syy_fine_row)
+    if (spread) {  // one row of 16 lanes per stream (see sweep_syy_fine_row_x)
       float *ag = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
       fbp_sweep_row(ag + SCR_SYY, ag[SCR_MAIL + MAIL_SYY0C], lane & 15);
     } else {

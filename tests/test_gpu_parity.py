@@ -588,13 +588,16 @@ def test_throughput_kernels_at_small_sizes():
     """Small batches run the latency-oriented kernels by default (rn_hp_one_kernel up to 3072 streams, rn_nn_one_kernel up to
     512 on the vector path); with both switched off ($RNNOISE_AMD_HP_ONE_MAX / $RNNOISE_AMD_NN_ONE_MAX = 0, read once per
     process) the same cases go through rn_hp_kernel and rn_nn_vector_kernel -- the kernels of larger batches -- and must give
-    the same bits"""
+    the same bits; $RNNOISE_AMD_K1_SPW=4 adds the four-stream analysis workgroups of large batches, tails included"""
     import os
     import subprocess
     import sys
     if os.environ.get("RNNOISE_AMD_NN_ONE_MAX"):
         pytest.skip("already inside a forced run")
-    env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0")
+    # ... and with four streams per analysis workgroup (rn_analysis_kernel, the form of batches from 6144 streams up): the batch
+    # sizes of these cases are not multiples of four, so the tail workgroup's surplus waves -- which redo the last stream, meet
+    # every barrier and lend their arenas to the narrow phases' row and pair passes -- are exercised too
+    env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0", RNNOISE_AMD_K1_SPW="4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, os.path.join(root, "tests", "test_blob_tools.py"), "-k",
                         "test_mfma_path_bit_exact or test_synthetic_models_on_gpu or test_s16_entry_points or test_drop_in_single_stream_api"],
