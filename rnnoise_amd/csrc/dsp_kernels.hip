@@ -802,9 +802,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   AnalysisLds &L = arenas[wave];
   float *mail = L.a + SCR_MAIL;
   // a tail workgroup's surplus waves redo the last stream without storing anything: they still meet every barrier
-  const int s_raw = listed_row >= 0 ? listed_row : (int)blockIdx.x * SPW + wave;  // (a listed row: rn_dev.h RnRows, one-stream workgroups)
-  const bool wr = s_raw < g.n_streams;
-  const int s = wr ? s_raw : g.n_streams - 1;
+  // (a listed row: rn_dev.h RnRows.  In a workgroup of several waves ALL of them then work on that one row and only wave 0
+  //  stores: the others are there for the narrow phases -- see rn_analysis_rows_kernel)
+  const int s_raw = listed_row >= 0 ? listed_row : (int)blockIdx.x * SPW + wave;
+  const bool in_range = s_raw < g.n_streams;
+  const bool wr = in_range && (listed_row < 0 || wave == 0);
+  const int s = in_range ? s_raw : g.n_streams - 1;
 // workgroup barrier between a stream's own wave and wave 0 (a wavefront fence when the workgroup is one wave)
 #define WG_SYNC()                      \
   do {                                 \
@@ -1438,6 +1441,17 @@ rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, Rn
                           listed ? (int)(re & 255u) : -1);
 }
 
+// A launch group of the one-frame API, for LATENCY: one workgroup of K1_SPW waves per listed row, every wave working on that
+// row's frame.  The waves do the same wide work four times over (on four SIMDs that have nothing else to do: a group is at most
+// 64 rows on 256 CUs) so that the frame's serial chains run side by side as in the batched kernel -- the fine
+// cross-correlations beside the start energy and the fine running energy, the candidate dots beside yy_lookup -- instead of one
+// after the other on the stream's only wave.  Only wave 0 stores.
+extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
+rn_analysis_rows_kernel(RnGroupDev g, RnTablesDev tb, RnRows rows) {
+  const uint32_t re = rows.e[blockIdx.x];
+  analysis_body<false, K1_SPW>(g, tb, (int)((re >> 8) & 7u), (int)((re >> 12) & 3u), RnTrainArgs{}, (int)(re & 255u));
+}
+
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_train_features_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, RnTrainArgs tr) {
@@ -1682,7 +1696,10 @@ extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev
 }
 // K1 / K3 of a launch group of the one-frame API (rn_dev.h: RnRows): one one-wave workgroup per listed row
 extern "C" hipError_t rn_launch_analysis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
-  hipLaunchKernelGGL(rn_analysis_single_kernel, dim3(rows->n), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, 0, 0, *rows);
+  // RNNOISE_AMD_ROWS_K1=1 (A/B runs): one wave per row (rn_analysis_single_kernel) instead of a workgroup of four
+  static const bool one_wave = [] { const char *e = getenv("RNNOISE_AMD_ROWS_K1"); return e && atoi(e) == 1; }();
+  if (one_wave) hipLaunchKernelGGL(rn_analysis_single_kernel, dim3(rows->n), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, 0, 0, *rows);
+  else hipLaunchKernelGGL(rn_analysis_rows_kernel, dim3(rows->n), dim3(WAVE * K1_SPW), K1_SPW * sizeof(AnalysisLds), st, *g, *tb, *rows);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
