@@ -808,6 +808,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const bool in_range = s_raw < g.n_streams;
   const bool wr = in_range && (listed_row < 0 || wave == 0);
   const int s = in_range ? s_raw : g.n_streams - 1;
+  // ... and only wave 0 does the frame's wide work at all: the other waves go from barrier to barrier and serve the narrow
+  // phases, every row of which then points at wave 0's arena (`solo`; the rows repeat one chain on the same addresses)
+  const bool solo = SPW > 1 && listed_row >= 0;
+  const bool active = !solo || wave == 0;
+#define ARENA(i) arenas[solo ? 0 : (i)]
 // workgroup barrier between a stream's own wave and wave 0 (a wavefront fence when the workgroup is one wave)
 #define WG_SYNC()                      \
   do {                                 \
@@ -864,6 +869,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   };
   // ---- rnn_frame_analysis (src/denoise.c:332-345): window [prev | cur], FFT, Ex ----
   float *gX = g.spec_X[parity] + (size_t)s * RN_SPEC_STRIDE;
+  float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
+  int bp0 = 0, bp1 = 0, pitch_index = 0;
+  float xx = 0.f;
+  if (active) {  // ======== wide stretch A: transform of X, Ex, downsampling, coarse cross-correlations
   {
     float xr[15], xi[15];
     window_to_regs(xr, xi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE, tb.half_window);
@@ -935,7 +944,6 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   K1_STOP(4);
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
-  float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC;
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
   float syy0_coarse;
   {
@@ -974,12 +982,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     syy0_coarse = lane_bcast(r.p.x, 31);
   }
   RN_WSYNC();
-  int bp0, bp1;
   CLK_TAP(4);  // coarse xcorr
   K1_STOP(6);
-  float *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
   fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
   if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
+  }  // ======== (A)
   WG_SYNC();
   if (wave == nw1) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
     // The other waves of the workgroup wait for this one, and its chains are dependent instructions: it takes every issue
@@ -987,7 +994,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     // three waves of other workgroups on its SIMD, which have independent work for the remaining slots.
     if (SPW > 1) __builtin_amdgcn_s_setprio(3);
     if (spread) {  // one row of 16 lanes per stream (see sweep_syy_fine_row_x)
-      float *ag = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+      float *ag = ARENA((lane >> 4) < SPW ? (lane >> 4) : 0).a;
       fbp_sweep_row(ag + SCR_SYY, ag[SCR_MAIL + MAIL_SYY0C], lane & 15);
     } else {
       const int gi = lane < SPW ? lane : 0;
@@ -996,6 +1003,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if (SPW > 1) __builtin_amdgcn_s_setprio(1);
   }
   WG_SYNC();
+  if (active) {  // ======== wide stretch B: coarse selection, the shifted copy
   best_pitch_select(xc, scr + SCR_SYY, 147, bp0, bp1, lane);
   CLK_TAP(5);  // coarse best-pitch scan
   K1_STOP(7);
@@ -1021,6 +1029,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     mail[MAIL_BP0] = __int_as_float(bp0);
     mail[MAIL_BP1] = __int_as_float(bp1);
   }
+  }  // ======== (B)
   K1_STOP(8);
   WG_SYNC();
   if (spread) {
@@ -1034,7 +1043,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if (wave == nw2) {
       if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
       const int gq = lane >> 4, r = lane & 15;  // (SPW == 4 rows)
-      float *ag = arenas[gq < SPW ? gq : 0].a;
+      float *ag = ARENA(gq < SPW ? gq : 0).a;
       const int b0 = __float_as_int(ag[SCR_MAIL + MAIL_BP0]), b1 = __float_as_int(ag[SCR_MAIL + MAIL_BP1]);
       const int c = (r < 5) ? (2 * b0 - 2 + r) : (2 * b1 - 2 + (r - 5));
       const bool lag = r < 10 && c >= 0 && c < 294;
@@ -1047,7 +1056,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     } else if (wave == nw3a) {
       if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
       {  // (every lane takes part: the rows' DPP operands come from the other lanes' registers)
-        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+        float *a = ARENA((lane >> 4) < SPW ? (lane >> 4) : 0).a;
         const float syy0 = chain_sq_row(to_lds(a + SCR_XLP), 480, 1.f, lane & 15);
         sweep_syy_fine_row_x(a + SCR_XLP, a + SCR_D, syy0, lane & 15);
       }
@@ -1078,7 +1087,8 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   WG_SYNC();
   K1_STOP(9);
-  const float xx = mail[MAIL_XX];
+  if (active) {  // ======== wide stretch C: fine selection
+  xx = mail[MAIL_XX];
   best_pitch_select(xc, Dsyy - 1, 294, bp0, bp1, lane);
   CLK_TAP(7);  // fine best-pitch selection
   K1_STOP(10);
@@ -1088,11 +1098,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if ((c - a) > .7f * (b - a)) offset = 1;
     else if ((a - c) > .7f * (b - c)) offset = -1;
   }
-  int pitch_index = RN_PITCH_MAX_PERIOD - (2 * bp0 - offset);
+  pitch_index = RN_PITCH_MAX_PERIOD - (2 * bp0 - offset);
   if (dbg) {
     for (int i = lane; i < 294; i += WAVE) dbg[RN_DBG_XC_FINE + i] = xc[i];
     if (lane == 0) { dbg[RN_DBG_BEST + 2] = bp0; dbg[RN_DBG_BEST + 3] = bp1; dbg[RN_DBG_BEST + 4] = offset; dbg[RN_DBG_BEST + 5] = pitch_index; }
   }
+  }  // ======== (C)
 
   // ---- rnn_remove_doubling (src/pitch.c:423-528): maxperiod 384, minperiod 30, N 480 ----
   float pgain;
@@ -1182,17 +1193,18 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     if (spread) {
       if (wave == nw1 || wave == nw3b) {
         if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
-        float *ag = arenas[(wave == nw1 ? 0 : 2) + (lane >> 5)].a;
+        float *ag = ARENA((wave == nw1 ? 0 : 2) + (lane >> 5)).a;
         const int T0g = __float_as_int(ag[SCR_MAIL + MAIL_T0]);
         candidate_dots(ag, T0g, lane & 31);
         __builtin_amdgcn_s_setprio(1);
       } else if (wave == nw2) {  // yy_lookup of every stream, one row each (every lane takes part: DPP operands)
         if (narrow_prio == 3) __builtin_amdgcn_s_setprio(3);
-        float *a = arenas[(lane >> 4) < SPW ? (lane >> 4) : 0].a;
+        float *a = ARENA((lane >> 4) < SPW ? (lane >> 4) : 0).a;
         sweep_yy_lookup_row_x(a + SCR_XLP, a + SCR_YYL, a[SCR_MAIL + MAIL_XX], lane & 15);
         __builtin_amdgcn_s_setprio(1);
       }
       __syncthreads();
+      if (!active) return;  // (that was the last barrier: the surplus waves of a one-row workgroup are done)
     } else {
       candidate_dots(scr, T0, lane);
     }
@@ -1417,6 +1429,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   }
   CLK_TAP(11);  // window + FFT(P) + Ep + Exp + features
 }
+#undef ARENA
 
 // (4 waves per SIMD is what the LDS allows: 16 arenas of 10 KB per CU; without the cap the allocator spreads to 154 VGPRs)
 extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
