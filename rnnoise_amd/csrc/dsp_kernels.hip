@@ -545,6 +545,50 @@ __device__ __forceinline__ float chain_sq_row(ldsf y, int n, float s0, int l16) 
   return s;
 }
 
+// One lag of the 5-lag autocorrelation of rnn_pitch_downsample (src/celt_lpc.c:92-174) as a row chain: 860 terms
+// x[i] * x[i + lag] in order (rnn_pitch_xcorr over fastN), then the tail chain of the terms i = 860 .. 863 - lag, then their
+// sum -- what lane `lag` of rn_hp_one_kernel computes, 19 instructions per 16 terms instead of 64.  Excluded tail terms enter
+// as +0.0f (a sum that starts at +0 never becomes -0: adding +0 changes no bit).  Every lane of the row returns the value.
+template <int K, int N>
+struct AcRowSteps {
+  static __device__ __forceinline__ void run(float &s, float p) {
+    s = s + row_bcast<K>(p);
+    AcRowSteps<K + 1, N>::run(s, p);
+  }
+};
+template <int N>
+struct AcRowSteps<N, N> {
+  static __device__ __forceinline__ void run(float &, float) {}
+};
+__device__ __forceinline__ float autocorr_row(ldsf x, int lag, int l16) {
+  float s = 0.f;
+  ldsf xa = x + l16, xb = x + lag + l16;
+  float a = xa[0], b = xb[0], an = xa[16], bn = xb[16];
+#pragma unroll 1
+  for (int i = 0; i < 848; i += 16) {  // 53 whole blocks
+    float p = a * b;
+    OPAQUE(p);
+    a = an;
+    b = bn;
+    an = xa[i + 32];  // (two blocks ahead; past the signal's end the values are read and never added)
+    bn = xb[i + 32];
+    AcRowSteps<0, 16>::run(s, p);
+  }
+  {  // terms 848 .. 859
+    float p = a * b;
+    OPAQUE(p);
+    AcRowSteps<0, 12>::run(s, p);
+  }
+  float d = 0.f;
+  {
+    const int i = 860 + (l16 & 3);
+    float p = (l16 < 4 && i + lag <= 863) ? x[i + lag] * x[i] : 0.f;
+    OPAQUE(p);
+    AcRowSteps<0, 4>::run(d, p);
+  }
+  return s + d;
+}
+
 // chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
 // For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
 // dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
@@ -872,6 +916,36 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
   int bp0 = 0, bp1 = 0, pitch_index = 0;
   float xx = 0.f;
+  // 2x decimation of pitch_buf into this wave's x_lp (src/pitch.c:155-166)
+  auto decimate_to_xlp = [&]() {
+#pragma unroll 7
+    for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
+      const int i0 = lane + WAVE * t, i = i0 < 864 ? i0 : 863;  // clamp, not a branch
+      // pitch_buf[2i] sits at an even ring position, so {b, c} is one aligned 8-byte load that never straddles the wrap; the
+      // left neighbour may (sample 0 has none: its load is aimed at a valid address and dropped)
+      const unsigned pe = (unsigned)ring0 + 2u * (unsigned)i, pl_ = (unsigned)max((int)pe - 1, ring0);
+      const float2 bc = *reinterpret_cast<const float2 *>(ring + min(pe, pe - (unsigned)RN_RING_SIZE));
+      const float a = ring[min(pl_, pl_ - (unsigned)RN_RING_SIZE)], b = bc.x, c = bc.y;
+      float v = .5f * (.5f * (a + c) + b);
+      if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
+      xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
+    }
+  };
+  // One-row workgroups: the 5 autocorrelation lags behind the FIR taps are formed HERE, by two spare waves (lags 0..3 on the
+  // four rows of wave 1, lag 4 on wave 2, each over its own decimated copy of pitch_buf in its own arena), while wave 0
+  // transforms X -- the high-pass kernel of such a row stops after the ring store.  The lags meet wave 0 at a barrier in front
+  // of its FIR; the lag window and the Levinson recursion (rn_dev.h) it runs itself.
+  float *ac_mail = scr + SCR_EX;  // (a spare wave's Ex area is free)
+  if (solo && !active) {
+    if (wave == 1 || wave == 2) {
+      decimate_to_xlp();
+      RN_WSYNC();
+      const int row = lane >> 4, lag = wave == 1 ? row : 4;
+      const float acv = autocorr_row(to_lds(xlp), lag, lane & 15);
+      if ((lane & 15) == 0 && (wave == 1 || row == 0)) ac_mail[lag] = acv;
+    }
+    __syncthreads();
+  }
   if (active) {  // ======== wide stretch A: transform of X, Ex, downsampling, coarse cross-correlations
   {
     float xr[15], xi[15];
@@ -897,23 +971,20 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   CLK_TAP(2);  // window + FFT(X) + Ex
   K1_STOP(3);
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
-#pragma unroll 7
-  for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
-    const int i0 = lane + WAVE * t, i = i0 < 864 ? i0 : 863;  // clamp, not a branch
-    // pitch_buf[2i] sits at an even ring position, so {b, c} is one aligned 8-byte load that never straddles the wrap; the
-    // left neighbour may (sample 0 has none: its load is aimed at a valid address and dropped)
-    const unsigned pe = (unsigned)ring0 + 2u * (unsigned)i, pl_ = (unsigned)max((int)pe - 1, ring0);
-    const float2 bc = *reinterpret_cast<const float2 *>(ring + min(pe, pe - (unsigned)RN_RING_SIZE));
-    const float a = ring[min(pl_, pl_ - (unsigned)RN_RING_SIZE)], b = bc.x, c = bc.y;
-    float v = .5f * (.5f * (a + c) + b);
-    if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
-    xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
-  }
+  decimate_to_xlp();
   RN_WSYNC();
   // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
   float lpc2[5];
+  if (solo) {
+    __syncthreads();  // (the spare waves' lags are in place)
+    float acs[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) lpc2[k] = g.lpc2[((size_t)slot * g.n_stride + s) * 8 + k];
+    for (int k = 0; k < 5; k++) acs[k] = arenas[k < 4 ? 1 : 2].a[SCR_EX + k];
+    rn_fir_taps_from_ac(acs, lpc2);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; k++) lpc2[k] = g.lpc2[((size_t)slot * g.n_stride + s) * 8 + k];
+  }
   if (dbg && lane < 5) dbg[RN_DBG_LPC + lane] = lpc2[lane];
   {  // celt_fir5 in place (src/pitch.c:104-143): outputs are independent given the OLD samples
     float r[14];

@@ -135,46 +135,11 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
-    ac[0] *= 1.0001f;
-#pragma unroll
-    for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
-    float lpc[4] = {0, 0, 0, 0};
-    if (ac[0] != 0) {
-      float error = ac[0];
-      bool done = false;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (!done) {
-          float rr = 0;
-#pragma unroll
-          for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-          rr += ac[i + 1];
-          const float r = -rr / error;
-          lpc[i] = r;
-#pragma unroll
-          for (int j = 0; j < (i + 1) >> 1; j++) {
-            const float t1 = lpc[j], t2 = lpc[i - 1 - j];
-            lpc[j] = t1 + r * t2;
-            lpc[i - 1 - j] = t2 + r * t1;
-          }
-          error = error - (r * r) * error;
-          if (error < .001f * ac[0]) done = true;  // `break` (celt_lpc.c:81-82)
-        }
-      }
-    }
-    float tmp = 1.f;
-    const float c1 = .8f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      tmp = .9f * tmp;
-      lpc[i] = lpc[i] * tmp;
-    }
+    float taps[5];
+    rn_fir_taps_from_ac(ac, taps);  // (lag window, Levinson, bandwidth expansion: rn_dev.h)
     float *o = g.lpc2 + ((size_t)slot * g.n_stride + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
-    o[0] = lpc[0] + .8f;
-    o[1] = lpc[1] + c1 * lpc[0];
-    o[2] = lpc[2] + c1 * lpc[1];
-    o[3] = lpc[3] + c1 * lpc[2];
-    o[4] = c1 * lpc[3];
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[k] = taps[k];
     if (RN_INSTRUMENT && g.debug) {
 #pragma unroll
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
@@ -282,6 +247,10 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 #pragma unroll
     for (int i = 0; i < 2; i++)
       if (lane + 64 * i < RN_FRAME_SIZE / 4) y[lane + 64 * i] = src[lane + 64 * i];
+    // a listed row whose analysis runs as a four-wave workgroup gets its 5 FIR taps there, on a spare wave, beside the
+    // transform of X (rn_analysis_rows_kernel): the lags, a third of this kernel's time, are not formed here (bit 8 of
+    // slot_arg set by the launcher: they ARE wanted -- the one-wave analysis of $RNNOISE_AMD_ROWS_K1=1)
+    if (listed && !(slot_arg & 256)) return;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
       const int t = lane + 64 * i;
@@ -309,47 +278,12 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
   float ac[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) ac[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acl), k));  // (the builtin moves ints)
-  ac[0] *= 1.0001f;
-#pragma unroll
-  for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
-  float lpc[4] = {0, 0, 0, 0};
-  if (ac[0] != 0) {  // order-4 Levinson (src/celt_lpc.c:38-89), the same on every lane
-    float error = ac[0];
-    bool done = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (!done) {
-        float rr = 0;
-#pragma unroll
-        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
-        rr += ac[i + 1];
-        const float r = -rr / error;
-        lpc[i] = r;
-#pragma unroll
-        for (int j = 0; j < (i + 1) >> 1; j++) {
-          const float t1 = lpc[j], t2 = lpc[i - 1 - j];
-          lpc[j] = t1 + r * t2;
-          lpc[i - 1 - j] = t2 + r * t1;
-        }
-        error = error - (r * r) * error;
-        if (error < .001f * ac[0]) done = true;
-      }
-    }
-  }
-  float tmp = 1.f;
-  const float c1 = .8f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    tmp = .9f * tmp;
-    lpc[i] = lpc[i] * tmp;
-  }
+  float taps[5];
+  rn_fir_taps_from_ac(ac, taps);  // (lag window, Levinson, bandwidth expansion: rn_dev.h; the same on every lane)
   if (lane == 0) {
     float *o = g.lpc2 + ((size_t)slot * g.n_stride + s) * 8;
-    o[0] = lpc[0] + .8f;
-    o[1] = lpc[1] + c1 * lpc[0];
-    o[2] = lpc[2] + c1 * lpc[1];
-    o[3] = lpc[3] + c1 * lpc[2];
-    o[4] = c1 * lpc[3];
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[k] = taps[k];
     if (RN_INSTRUMENT && g.debug) {
 #pragma unroll
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
@@ -377,6 +311,7 @@ extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float 
 }
 // K0 of a launch group of the one-frame API (rn_dev.h: RnRows): one wave per listed row, float frames from the pool's pinned blocks
 extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *g, const RnRows *rows, hipStream_t st) {
-  hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), 0, 0, *rows);
+  static const int taps_here = [] { const char *e = getenv("RNNOISE_AMD_ROWS_K1"); return (e && atoi(e) == 1) ? 256 : 0; }();  // (dsp_kernels.hip: rn_launch_analysis_rows)
+  hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), taps_here, 0, *rows);
   return hipGetLastError();
 }

@@ -158,6 +158,50 @@ __device__ __forceinline__ float rn_rcp_x86(float x, const uint16_t *lut16) {
   const uint32_t v = lut16[(b >> 11) & 0xfff];
   return __uint_as_float((v << 11) + (RN_RCP_K - (b & 0x7f800000u)));
 }
+// The 5 FIR taps of rnn_pitch_downsample from the 5 raw autocorrelation lags (src/pitch.c:176-199: lag window, order-4
+// Levinson of src/celt_lpc.c:38-89, bandwidth expansion, the c1 = .8 zero): one body for the high-pass kernels, which
+// compute the lags lane- or wave-per-stream, and for the one-row analysis workgroup, which computes them on a spare wave.
+__device__ __forceinline__ void rn_fir_taps_from_ac(float (&ac)[5], float (&o)[5]) {
+  ac[0] *= 1.0001f;
+#pragma unroll
+  for (int i = 1; i <= 4; i++) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+  float lpc[4] = {0, 0, 0, 0};
+  if (ac[0] != 0) {
+    float error = ac[0];
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (!done) {
+        float rr = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) rr += lpc[j] * ac[i - j];
+        rr += ac[i + 1];
+        const float r = -rr / error;
+        lpc[i] = r;
+#pragma unroll
+        for (int j = 0; j < (i + 1) >> 1; j++) {
+          const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+          lpc[j] = t1 + r * t2;
+          lpc[i - 1 - j] = t2 + r * t1;
+        }
+        error = error - (r * r) * error;
+        if (error < .001f * ac[0]) done = true;  // `break` (celt_lpc.c:81-82)
+      }
+    }
+  }
+  float tmp = 1.f;
+  const float c1 = .8f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    tmp = .9f * tmp;
+    lpc[i] = lpc[i] * tmp;
+  }
+  o[0] = lpc[0] + .8f;
+  o[1] = lpc[1] + c1 * lpc[0];
+  o[2] = lpc[2] + c1 * lpc[1];
+  o[3] = lpc[3] + c1 * lpc[2];
+  o[4] = c1 * lpc[3];
+}
 #include <hip/hip_ext.h>
 // Launch with optional start / stop events: they are bound to the dispatch packet itself (hipExtLaunchKernel), so
 // timing a kernel or publishing its completion to another stream adds no packets to the queue.
