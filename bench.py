@@ -74,6 +74,7 @@ NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
 HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "3072"))
 K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))
 K1_MULTI_MIN_STREAMS = 6144
+K3_FEW_MAX_STREAMS = 256
 N_CU = 256
 NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
 
@@ -90,6 +91,8 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
         return "rn_analysis_single_kernel"  # one stream per workgroup
     if kind == "highpass" and n_streams <= HP_ONE_MAX_STREAMS:
         return "rn_hp_one_kernel"           # one wave per stream
+    if kind == "synthesis" and n_streams <= K3_FEW_MAX_STREAMS:
+        return "rn_synthesis_few_kernel"    # every operand requested up front (dsp_kernels.hip: RN_K3_FEW_MAX)
     return KERNEL_OF[kind]
 
 

@@ -971,12 +971,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   CLK_TAP(2);  // window + FFT(X) + Ex
   K1_STOP(3);
   // ---- rnn_pitch_downsample (src/pitch.c:146-214) ----
-  decimate_to_xlp();
+  // (one-row workgroups: wave 1 has decimated pitch_buf already -- the FIR below takes its input from that wave's arena)
+  if (!solo) decimate_to_xlp();
   RN_WSYNC();
+  const float *xdec = solo ? arenas[1].a + SCR_XLP : xlp;
   // the 5 FIR taps (autocorrelation + Levinson) were computed by the lane-per-stream kernel K0
   float lpc2[5];
   if (solo) {
-    __syncthreads();  // (the spare waves' lags are in place)
+    __syncthreads();  // (the spare waves' lags, and wave 1's decimated signal, are in place)
     float acs[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) acs[k] = arenas[k < 4 ? 1 : 2].a[SCR_EX + k];
@@ -993,12 +995,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       int i = lane + WAVE * t;
       float sum = 0;
       if (i < 864) {
-        sum = xlp[i];
-        sum = sum + lpc2[0] * (i >= 1 ? xlp[i - 1] : 0.f);
-        sum = sum + lpc2[1] * (i >= 2 ? xlp[i - 2] : 0.f);
-        sum = sum + lpc2[2] * (i >= 3 ? xlp[i - 3] : 0.f);
-        sum = sum + lpc2[3] * (i >= 4 ? xlp[i - 4] : 0.f);
-        sum = sum + lpc2[4] * (i >= 5 ? xlp[i - 5] : 0.f);
+        sum = xdec[i];
+        sum = sum + lpc2[0] * (i >= 1 ? xdec[i - 1] : 0.f);
+        sum = sum + lpc2[1] * (i >= 2 ? xdec[i - 2] : 0.f);
+        sum = sum + lpc2[2] * (i >= 3 ? xdec[i - 3] : 0.f);
+        sum = sum + lpc2[3] * (i >= 4 ? xdec[i - 4] : 0.f);
+        sum = sum + lpc2[4] * (i >= 5 ? xdec[i - 5] : 0.f);
       }
       r[t] = sum;
     }
@@ -1565,8 +1567,11 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 #ifndef RN_K3_WAVES
 #define RN_K3_WAVES 5  // (A/B builds: -DRN_K3_WAVES=6 spills 12 registers)
 #endif
-extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(RN_K3_WAVES, RN_K3_WAVES)))
-rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
+// LATE: the overlap-add operands behind the transform (the throughput form); !LATE: with everything else at the top (a handful of
+// waves on an empty machine have nobody to cover the extra round trip: rn_synthesis_few_kernel)
+template <bool LATE>
+__device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTablesDev &tb, float *__restrict__ out, int parity_arg, int prev_arg,
+                                               const RnRows &rows) {
   // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
   // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
   // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
@@ -1611,6 +1616,17 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   // (src/denoise.c:213-216).  n < 480: out[n] = 960*y*w[n] + synthesis_mem[n];  n >= 480: synthesis_mem[n - 480] =
   // 960*y*w[959 - n] = 960*y*w[p - 1]  (src/denoise.c:400-407).
   float *sm = g.synth_mem + (size_t)s * RN_FRAME_SIZE;
+  float smv[15], wv[15];
+  if (!LATE) {
+#pragma unroll
+    for (int b = 0; b < 15; b++) {
+      const int p = WAVE * b + pos;
+      const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
+      const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
+      wv[b] = tb.half_window[n];
+      smv[b] = lo ? sm[n] : 0.f;
+    }
+  }
 
 // src/denoise.c:140-154 per bin (bins >= 400 -> 0), from a 32-entry band vector in LDS
 #define BAND(j) ((int)(bq[j] >> 22))
@@ -1696,8 +1712,7 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
   // transform: 142 VGPRs, three waves per SIMD, 0.29 ms at 65,536 streams; behind the transform the kernel needs 96, five
   // waves fit, and four of them cover the fifth's wait for these loads: 0.237 ms (profiles/r4_k3_occupancy.txt).  The index
   // goes through an empty asm together with a transform output so that the scheduler cannot hoist the loads back up.
-  float smv[15], wv[15];
-  {
+  if (LATE) {
     int pos_late = pos;
     asm volatile("" : "+v"(pos_late), "+v"(yr[14]));
 #pragma unroll
@@ -1738,6 +1753,16 @@ rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int p
                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(RN_K3_WAVES, RN_K3_WAVES)))
+rn_synthesis_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
+  synthesis_body<true>(g, tb, out, parity_arg, prev_arg, rows);
+}
+// the launch groups of the one-frame API and batches of up to RN_K3_FEW_MAX streams (one frame: 10.4 -> 9.6 us)
+#define RN_K3_FEW_MAX 256
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_synthesis_few_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
+  synthesis_body<false>(g, tb, out, parity_arg, prev_arg, rows);
+}
 
 // host-visible launch helpers -----------------------------------------------------------------
 // (K0 lives in hp_kernel.hip; K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream)
@@ -1774,8 +1799,12 @@ extern "C" hipError_t rn_launch_train_features(const RnGroupDev *g, const RnTabl
 }
 extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev *tb, void *out, int out_s16, int cur, int prev,
                                           hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, static_cast<float *>(out),
-            cur | (out_s16 ? 256 : 0), prev, RnRows{});
+  if (g->n_streams <= RN_K3_FEW_MAX)
+    RN_LAUNCH(rn_synthesis_few_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, static_cast<float *>(out),
+              cur | (out_s16 ? 256 : 0), prev, RnRows{});
+  else
+    RN_LAUNCH(rn_synthesis_kernel, dim3(g->n_streams), dim3(WAVE), sizeof(SynthLds), st, e0, e1, *g, *tb, static_cast<float *>(out),
+              cur | (out_s16 ? 256 : 0), prev, RnRows{});
   return hipGetLastError();
 }
 // K1 / K3 of a launch group of the one-frame API (rn_dev.h: RnRows): one one-wave workgroup per listed row
@@ -1787,6 +1816,6 @@ extern "C" hipError_t rn_launch_analysis_rows(const RnGroupDev *g, const RnTable
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_synthesis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
-  hipLaunchKernelGGL(rn_synthesis_kernel, dim3(rows->n), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, static_cast<float *>(nullptr), 0, 0, *rows);
+  hipLaunchKernelGGL(rn_synthesis_few_kernel, dim3(rows->n), dim3(WAVE), sizeof(SynthLds), st, *g, *tb, static_cast<float *>(nullptr), 0, 0, *rows);
   return hipGetLastError();
 }

@@ -23,6 +23,7 @@ def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
     for k in bench.NN_LAYER_KERNELS:  # every launch of the layer-wise network has its own PMC record
         assert bench.pmc_record(k, 65536)["hbm_bytes_per_frame"] > 1000, k
     assert bench.pmc_record("rn_nn_vector_kernel", 4096) is None  # never profiled with PMC: traffic is reported as null
+    assert bench.kernel_of("synthesis", 256) == "rn_synthesis_few_kernel" and bench.kernel_of("synthesis", 257) == "rn_synthesis_kernel"
 
 
 def test_algorithmic_bytes_match_design_table():
