@@ -592,8 +592,8 @@ __device__ __forceinline__ float autocorr_row(ldsf x, int lag, int l16) {
 // chain_dot8 with the y operand fetched two steps per LDS instruction: y2 = 8-byte aligned address of {y[0], y[1]}.
 // For an arbitrary (odd) start the caller points y2 into a copy of the signal shifted by one sample (see the doubling
 // dots): half the LDS instructions, and the per-lane-offset reads collide on 32 eight-byte slots instead of 32 banks.
-__device__ __forceinline__ float chain_dot8_y2(ldsf x, ldsf y2, int n) {
-  float s = 0.f;
+__device__ __forceinline__ float chain_dot8_y2(ldsf x, ldsf y2, int n, float s0 = 0.f) {
+  float s = s0;
   v4f_ xa = lds_read16(x), xb = lds_read16(x + 4);
   v2f ya[4];
 #pragma unroll
@@ -946,6 +946,24 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     }
     __syncthreads();
   }
+  // ... and the coarse search's 147 cross-correlations + start energy are split over the four waves: one chain per lane (49 lags
+  // on each of waves 0..2, the energy on wave 3) instead of three per lane on wave 0 -- the same products in the same order per
+  // chain (chain_dot8_y2 is the scalar chain of chain_dot8_x3), results into wave 0's arena.
+  auto coarse_chains_solo = [&]() {
+    float *a0 = arenas[0].a;
+    if (wave < 3) {
+      const int lag = 49 * wave + (lane < 49 ? lane : 48);
+      const float v = chain_dot8_y2(to_lds(a0 + SCR_Y4 + 192), to_lds(a0 + ((lag & 1) ? SCR_Y4S + (lag - 1) : SCR_Y4 + lag)), 240);
+      if (lane < 49) a0[SCR_XC + lag] = v;
+    } else {
+      const float e = chain_dot8_y2(to_lds(a0 + SCR_Y4), to_lds(a0 + SCR_Y4), 240, 1.f);
+      if (lane == 0) a0[SCR_MAIL + MAIL_SYY0C] = e;
+    }
+  };
+  if (solo && !active) {
+    __syncthreads();  // (wave 0's 4x-decimated signal is in place)
+    coarse_chains_solo();
+  }
   if (active) {  // ======== wide stretch A: transform of X, Ex, downsampling, coarse cross-correlations
   {
     float xr[15], xi[15];
@@ -1018,7 +1036,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   if (dbg) for (int i = lane; i < 864; i += WAVE) dbg[RN_DBG_XLP + i] = xlp[i];
   // ---- rnn_pitch_search (src/pitch.c:281-385), len 960, max_pitch 588 ----
   // 4x decimated lp[2j], j<432: y_lp4 = y4[0..386], x_lp4 = y4[192..431] (src/pitch.c:309-312)
-  float syy0_coarse;
+  float syy0_coarse = 0.f;
   {
     float *y4s = scr + SCR_Y4S;
     v2f *Z = reinterpret_cast<v2f *>(scr + SCR_Z);
@@ -1029,6 +1047,12 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       y4[j] = v;
       if (j >= 1) y4s[j - 1] = v;  // y4s[i] = y4[i + 1] (only i < 386 is read)
     }
+    if (solo) {  // (one-row workgroups: see coarse_chains_solo)
+      RN_WSYNC();
+      fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
+      __syncthreads();
+      coarse_chains_solo();
+    } else {
 #pragma unroll
     for (int t = 0; t < 5; t++) {  // 289 pairs
       const int j0 = lane + WAVE * t, j = j0 < 289 ? j0 : 288;
@@ -1053,12 +1077,15 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       xc[l3 + 98] = r.q;
     }
     syy0_coarse = lane_bcast(r.p.x, 31);
+    }
   }
   RN_WSYNC();
   CLK_TAP(4);  // coarse xcorr
   K1_STOP(6);
-  fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
-  if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
+  if (!solo) {
+    fbp_increments(y4, 240, 147, scr + SCR_SYY, lane);
+    if (lane == 0) mail[MAIL_SYY0C] = syy0_coarse;
+  }
   }  // ======== (A)
   WG_SYNC();
   if (wave == nw1) {  // narrow phase 1: the coarse running energy of every stream of the workgroup, one lane each
