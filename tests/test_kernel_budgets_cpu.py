@@ -1,0 +1,83 @@
+"""The built kernels' register / scratch budgets and memory instructions, read from the code objects (no GPU): the occupancy the
+design counts on is a property of the compiled code, and it moved more than once with unrelated edits --
+rn_synthesis_kernel from 142 to 96 VGPRs is what makes it a five-waves-per-SIMD kernel, a flat_load in rn_analysis_kernel makes
+every LDS wait a memory wait."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+BUILD = os.path.join(ROOT, "rnnoise_amd", "csrc", "build")
+
+
+def _code_object(obj, td):
+    out, fat = os.path.join(td, "dev.co"), os.path.join(td, "fat.bin")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True, capture_output=True)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={out}"], check=True, capture_output=True)
+    return out
+
+
+def _kernels(obj):
+    with tempfile.TemporaryDirectory() as td:
+        co = _code_object(obj, td)
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+    meta = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        g = lambda k: (re.search(rf"\.{k}:\s*(\S+)", blk) or [None, "0"])[1]
+        meta[g("name")] = {k: int(g(k)) for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+    code, cur = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", ln)
+        if m:
+            cur = m.group(1)
+            code[cur] = []
+        elif cur and "\t" in ln:
+            code[cur].append(ln.split("\t")[1].split()[0] if len(ln.split("\t")) > 1 and ln.split("\t")[1].split() else "")
+    return meta, code
+
+
+@pytest.fixture(scope="module")
+def built():
+    objs = {n: os.path.join(BUILD, n + ".o") for n in ("dsp_kernels", "hp_kernel", "nn_layers", "nn_kernels", "nn_mfma")}
+    if not all(os.path.exists(p) for p in objs.values()):
+        pytest.skip("kernels not built (python -c 'import __graft_entry__ as g; g.build()')")
+    return {n: _kernels(p) for n, p in objs.items()}
+
+
+def test_register_budgets(built):
+    dsp, _ = built["dsp_kernels"]
+    for k in ("rn_analysis_kernel", "rn_analysis_rows_kernel", "rn_analysis_single_kernel"):
+        assert dsp[k]["vgpr_count"] <= 128 and dsp[k]["vgpr_spill_count"] == 0 and dsp[k]["private_segment_fixed_size"] == 0, (k, dsp[k])
+    # five waves per SIMD: 512 / 5 = 102 -> 96 with the allocation granule of 8
+    assert dsp["rn_synthesis_kernel"]["vgpr_count"] <= 96 and dsp["rn_synthesis_kernel"]["vgpr_spill_count"] == 0
+    assert dsp["rn_synthesis_few_kernel"]["vgpr_spill_count"] == 0
+    hp, _ = built["hp_kernel"]
+    assert hp["rn_hp_kernel"]["private_segment_fixed_size"] == 0 and hp["rn_hp_one_kernel"]["private_segment_fixed_size"] == 0
+    gru, _ = built["nn_layers"]
+    assert gru["rn_nn_gru_kernel"]["vgpr_count"] <= 256 and gru["rn_nn_gru_kernel"]["vgpr_spill_count"] == 0  # two waves per SIMD
+    assert gru["rn_nn_dense_kernel"]["vgpr_count"] <= 128
+    one, _ = built["nn_kernels"]
+    assert one["rn_nn_one_kernel"]["vgpr_spill_count"] <= 5  # (known: its 14-wave workgroup caps it at 128 VGPRs)
+
+
+def test_no_flat_or_scratch_memory_instructions_in_the_hot_kernels(built):
+    """a generic-pointer load (flat_load) counts on lgkmcnt as well as vmcnt: every wait for an LDS result then also waits for
+    global memory (round 4: 61 of them in rn_analysis_kernel, behind pointers that had gone through an empty asm)"""
+    for obj, names in (("dsp_kernels", ("rn_analysis_kernel", "rn_analysis_rows_kernel", "rn_analysis_single_kernel", "rn_synthesis_kernel",
+                                        "rn_synthesis_few_kernel")),
+                       ("hp_kernel", ("rn_hp_kernel", "rn_hp_one_kernel")), ("nn_layers", ("rn_nn_gru_kernel", "rn_nn_dense_kernel")),
+                       ("nn_mfma", ("rn_nn_front_kernel",))):
+        _, code = built[obj]
+        for k in names:
+            ins = code[k]
+            assert len(ins) > 200, (k, len(ins))
+            bad = [i for i in ins if i.startswith(("flat_load", "flat_store", "scratch_"))]
+            assert not bad, (k, bad[:5])
+    _, code = built["dsp_kernels"]
+    assert sum(i.startswith("s_barrier") for i in code["rn_analysis_kernel"]) == 6  # the workgroup barriers of the narrow phases
