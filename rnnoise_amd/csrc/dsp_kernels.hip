@@ -702,8 +702,10 @@ __device__ __forceinline__ float chain_dot16_xrow(ldsf x, ldsf y2, int n, int la
 //                  above the 481 bins that matter; small per-frame vectors in [2392,2560)
 //   coarse search: xlp [0,864) | y4 [864,1296) | y4 shifted by one [1344,1730) | interleaved pairs Z [1732,2310)
 //                  during the chains, then running energies [1728,1876) and xcorr [2028,2175)
-//   fine search  : xlp | reversed squares -> yy_lookup [864,1728) | energy increments -> Syy [1731,2028)
-//                  | xcorr [2028,2324) | 4 zeros [2324,2328); the doubling dots reuse [2120,2184)
+//   fine search  : xlp | x_lp shifted by one sample [864,1727) -- it stays until the doubling dots are through -- | Syy
+//                  [1731,2028) | xcorr [2028,2324); then yy_lookup [1731,2116) over the dead Syy / xcorr, doubling dots [2120,2184)
+//                  (one-stream workgroups, which run their chains themselves: reversed squares -> yy_lookup [864,1728) and
+//                  energy increments -> Syy [1731,2028) staged first, 4 zeros [2324,2328), the shifted copy made afterwards)
 // Three chains per lane against the same x: two lags as a 2-wide vector chain -- it compiles to v_pk_mul_f32 /
 // v_pk_add_f32, each component still mul-then-add in the reference order; z[k] = {y[k], y[k+49]} comes from an interleaved
 // copy, so a pair is one 8-byte LDS read that lands in an aligned register pair -- plus a scalar chain whose y operand comes
@@ -765,7 +767,7 @@ struct AnalysisLds {
   float a[2376];
 };
 #define SCR_XLP 0
-#define SCR_SQ 864    // [864]  fine search: reversed squares of xlp, later yy_lookup
+#define SCR_SQ 864    // [864]  one-stream workgroups: reversed squares of xlp, later yy_lookup
 #define SCR_Y4 864    // [432]  4x-decimated signal (coarse search only; over the not yet written squares)
 #define SCR_Y4S 1344  // [386]  the same shifted by one sample (8-byte reads at odd offsets); 480 floats after y4: the two copies'
                       //        8-byte slots interleave, so even and odd lanes of one read do not collide
@@ -775,8 +777,8 @@ struct AnalysisLds {
 #define SCR_XC 2028   // [296]  xcorr[] of pitch_search
 #define SCR_ZERO 2324 // [4]
 #define SCR_DOTS 2120 // [64]  doubling dots (behind yy_lookup, over the dead fine xcorr)
-#define SCR_YYL 1732  // [385] yy_lookup after the fine search (over the dead Syy / fine xcorr areas)
-#define SCR_XS 864    // [864] x_lp shifted by one sample, for the 8-byte reads of the doubling dots (over the dead squares)
+#define SCR_YYL 1732  // &yy_lookup[1] (16-byte aligned; yy_lookup[0] at 1731), [385] over the dead Syy / fine xcorr areas
+#define SCR_XS 864    // [863] x_lp shifted by one sample, for the 8-byte reads of the fine-search chains and the doubling dots
 #define SCR_Q 0       // [2 x RN_BAND_QSTRIDE] band products in the layout of RnTablesDev::band_q: over the staged window, which
                       //        is dead once the transform has its inputs; two arrays for the Ep / Exp pair
 #define SCR_EX 2336   // [32]  band energies of X: the one vector that lives from the first transform to the features
