@@ -1163,6 +1163,35 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         sweep_syy_fine_row_x(a + SCR_XLP, a + SCR_D, syy0, lane & 15);
       }
       __builtin_amdgcn_s_setprio(1);
+    } else if (solo && wave != 0 && wave == (nw3b != 0 ? nw3b : nw1)) {
+      // One-row workgroups: a wave with nothing to do in this phase forms the frame's first 32 features -- log10 of the band
+      // energies, the follower recurrence, their DCT (src/denoise.c:378-397) need Ex only, which wave 0 has had in its arena
+      // since the first transform -- and stores them; wave 0's tail then keeps just the energy sum behind `silence`.
+      const float *ex0 = arenas[0].a + SCR_EX;
+      float dcol[RN_NB_BANDS];
+#pragma unroll
+      for (int j = 0; j < RN_NB_BANDS; j++) dcol[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
+      if (lane < RN_NB_BANDS) Ly[lane] = (float)log10(1e-2 + (double)ex0[lane]);
+      RN_WSYNC();
+      float e_sum = 0;
+      {
+        float logMax = -2, follow = -2;
+        for (int i = 0; i < RN_NB_BANDS; i++) {
+          const float fd = follow - 1.5f;
+          const float ly = fmaxf(logMax - 7, fmaxf(fd, Ly[i]));
+          logMax = fmaxf(logMax, ly);
+          follow = fmaxf(fd, ly);
+          e_sum += ex0[i];
+          if (lane == 0) Ly[i] = ly;
+        }
+      }
+      RN_WSYNC();
+      if (lane < RN_NB_BANDS && in_range) {
+        float f_lo = dct_lane(Ly, dcol, tb);
+        if (lane == 0) f_lo -= 12;
+        if (lane == 1) f_lo -= 4;
+        g.features[(size_t)s * 68 + lane] = ((double)e_sum < 0.04) ? 0.f : f_lo;
+      }
     }
   } else {
     // one-stream workgroups: narrow phase 2 on 12 lanes -- lanes 0..9 the fine lags, lane 10 xx = <x, x> of remove_doubling,
@@ -1445,7 +1474,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float f_hi = 0;
   if (lane < RN_NB_BANDS) {
     f_hi = dct_lane(Exp, dctc, tb);
-    Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
+    if (!solo) Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
   }
   RN_WSYNC();
   // log-energy follower + total energy: 32 serial steps, evaluated uniformly.  The reference forms
@@ -1453,7 +1482,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // exact in double, rounding is monotonic and the other operands are floats, so
   // (float)max(follow-1.5, b) == max(follow-1.5f, b): the whole recurrence stays in float, same bits.
   float E = 0;
-  {
+  if (solo) {  // (the follower and the first 32 features came from a spare wave during narrow phase 2)
+    for (int i = 0; i < RN_NB_BANDS; i++) E += Ex[i];
+  } else {
     float logMax = -2, follow = -2;
     for (int i = 0; i < RN_NB_BANDS; i++) {
       // (the reference's MAX16 / MIN16 ternaries as v_max_f32: the same value for every non-NaN operand pair -- at most the sign
@@ -1473,10 +1504,13 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const int silence = TRAIN ? (((double)E < 0.1) ? 1 : 0) : (((double)E < 0.04) ? 1 : 0);
   const bool zero = !TRAIN && silence;
   if (lane < RN_NB_BANDS && wr) {
-    float f_lo = dct_lane(Ly, dctc, tb);
-    if (lane == 0) f_lo -= 12;
-    if (lane == 1) f_lo -= 4;
-    feat[lane] = zero ? 0.f : f_lo;
+    float f_lo = 0;
+    if (!solo) {
+      f_lo = dct_lane(Ly, dctc, tb);
+      if (lane == 0) f_lo -= 12;
+      if (lane == 1) f_lo -= 4;
+      feat[lane] = zero ? 0.f : f_lo;
+    }
     feat[RN_NB_BANDS + lane] = zero ? 0.f : f_hi;
     if (TRAIN) {
       tr.rec[(size_t)s * 98 + lane] = f_lo;
