@@ -26,6 +26,11 @@ RNNOISE_EXPORT int rnnoise_amd_debug_fft(int device, int variant, float *out, co
  * of the path whose device implementation differs from the host's). Host buffers. 0 / -1. */
 RNNOISE_EXPORT int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n);
 
+/* Race hunt (tools/gru_race.py): the log of the GRU layer kernel's checking instantiations ($RNNOISE_AMD_GRU_VARIANT=w4chk ...),
+ * 484 words: [0] h_old vectors that differed from HBM, [1] of them stale (= the previous unit tile's), [2] vectors checked,
+ * then 40 records of 12 words.  Reading clears it.  0 / -1. */
+RNNOISE_EXPORT int rnnoise_amd_debug_gru_race(int device, unsigned *log, int words);
+
 #ifdef __cplusplus
 }
 #endif

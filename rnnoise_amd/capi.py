@@ -57,7 +57,7 @@ def _share_hip_runtime_with_torch():
 
 
 # entry points of include/rnnoise_amd_debug.h: present in the instrumented library only
-DEBUG_EXPORTS = ["rnnoise_batch_debug_pitch", "rnnoise_amd_debug_fft", "rnnoise_amd_debug_log_energy"]
+DEBUG_EXPORTS = ["rnnoise_batch_debug_pitch", "rnnoise_amd_debug_fft", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_gru_race"]
 
 
 def lib():
@@ -137,6 +137,7 @@ def _load(path, debug):
         if debug:
             L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
             L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
+            L.rnnoise_amd_debug_gru_race.argtypes = [C.c_int, C.POINTER(C.c_uint), C.c_int]
             L.rnnoise_amd_debug_fft.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), ip]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]

@@ -284,7 +284,9 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
     // ordering between streams of ONE device: no system-scope fence (it writes back and invalidates the caches at
     // every record, which the next kernels then pay for)
-    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+    // ($RNNOISE_AMD_EVENT_FENCE=1, A/B runs only: ordering events with the system-scope fence back on)
+    static const bool sys_fence = [] { const char *e = getenv("RNNOISE_AMD_EVENT_FENCE"); return e && atoi(e) == 1; }();
+    const unsigned evf = hipEventDisableTiming | (sys_fence ? 0u : (unsigned)hipEventDisableSystemFence);
     HIP_OK(hipEventCreateWithFlags(&b->ev_begin, evf));
     for (int k = 0; k < 8; k++) {
       HIP_OK(hipEventCreateWithFlags(&b->own_hp[k], evf));
@@ -562,6 +564,15 @@ extern "C" int rnnoise_amd_debug_log_energy(int device, float *out, const float 
     rc = 0;
   hipFree(d);
   return rc;
+}
+
+// the GRU layer kernel's row-buffer check (nn_layers.hip: CHK instantiations): copies the log out and clears it
+extern "C" hipError_t rn_gru_race_log_read(unsigned *out, int words);
+extern "C" int rnnoise_amd_debug_gru_race(int device, unsigned *log, int words) {
+  if (!log) return -1;
+  ON_DEVICE(device);
+  HIP_OK(rn_gru_race_log_read(log, words));
+  return 0;
 }
 
 #endif  // RN_INSTRUMENT

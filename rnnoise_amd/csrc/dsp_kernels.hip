@@ -734,22 +734,29 @@ __device__ __forceinline__ XC3 chain_dot8_x3(ldsf x, ldsf z, ldsf y2, int n, v2f
     float p0 = xa.x * w[0].x, p1 = xa.y * w[0].y, p2 = xa.z * w[1].x, p3 = xa.w * w[1].y;
     float p4 = xb.x * w[2].x, p5 = xb.y * w[2].y, p6 = xb.z * w[3].x, p7 = xb.w * w[3].y;
     OPAQUE(p0); OPAQUE(p1); OPAQUE(p2); OPAQUE(p3); OPAQUE(p4); OPAQUE(p5); OPAQUE(p6); OPAQUE(p7);
-    s = s + v2f{xa.x, xa.x} * y[0];
+    // (x[1], x[3], ... sit in the HIGH register of their pair after the 16-byte read: broadcast into a packed multiply they
+    //  would be an op_sel operand, and packed-FP32 instructions with an op_sel bit are not allowed in this library --
+    //  profiles/r5_gru_race.txt, tests/test_kernel_budgets_cpu.py -- so their two products are scalar multiplies)
+#define X3_LO(xv, yv) s = s + v2f{xv, xv} * (yv)
+#define X3_HI(xv, yv) do { float a_ = (xv) * (yv).x, b_ = (xv) * (yv).y; OPAQUE(a_); OPAQUE(b_); s = s + v2f{a_, b_}; } while (0)
+    X3_LO(xa.x, y[0]);
     q = q + p0;
-    s = s + v2f{xa.y, xa.y} * y[1];
+    X3_HI(xa.y, y[1]);
     q = q + p1;
-    s = s + v2f{xa.z, xa.z} * y[2];
+    X3_LO(xa.z, y[2]);
     q = q + p2;
-    s = s + v2f{xa.w, xa.w} * y[3];
+    X3_HI(xa.w, y[3]);
     q = q + p3;
-    s = s + v2f{xb.x, xb.x} * y[4];
+    X3_LO(xb.x, y[4]);
     q = q + p4;
-    s = s + v2f{xb.y, xb.y} * y[5];
+    X3_HI(xb.y, y[5]);
     q = q + p5;
-    s = s + v2f{xb.z, xb.z} * y[6];
+    X3_LO(xb.z, y[6]);
     q = q + p6;
-    s = s + v2f{xb.w, xb.w} * y[7];
+    X3_HI(xb.w, y[7]);
     q = q + p7;
+#undef X3_LO
+#undef X3_HI
     xa = xc;
     xb = xd;
 #pragma unroll

@@ -1,7 +1,8 @@
 // hp_kernel.hip -- K0: the per-stream serial front end (high-pass, pitch-buffer decimation, 5-lag autocorrelation,
-// Levinson), transposed to lane = stream.  Kept in its own translation unit because it is compiled WITH the SLP
-// vectoriser (its unrolled float4 blocks pack well: ~9 % fewer instructions), whereas dsp_kernels.hip is compiled with
-// -fno-slp-vectorize (register-resident FFT: packed math there costs 40 VGPRs and the DPP folding of the exchanges).
+// Levinson), transposed to lane = stream.  Compiled WITHOUT the SLP vectoriser since round 5: with it (~9 % fewer
+// instructions) the autocorrelation chains became v_pk_mul_f32 / v_pk_add_f32 with op_sel operand selects, and those take the
+// wrong operand half in lanes 48..63 whenever a wave issuing v_mfma_i32_16x16x64_i8 shares the SIMD (profiles/r5_gru_race.txt;
+// tests/test_kernel_budgets_cpu.py keeps every such instruction out of the library).  hp_slp.hip is the old build, for A/B runs.
 // Numerics contract as in dsp_kernels.hip: -ffp-contract=off, reference order of every float sum.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,13 +19,19 @@
 // a0*yi and a1*yi are products of two 24-bit significands, exact in double, so
 // fma(-a, yi, b*xi) rounds once exactly like the reference's (b*xi - a*yi).
 // ---------------------------------------------------------------------------------------------
+#ifndef RN_HP_KERNEL_NAME
+#define RN_HP_KERNEL_NAME rn_hp_kernel
+#endif
 extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
+RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
   // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
   const int apply_hp = mode & 1, in_s16 = mode & 2;
   const int s = blockIdx.x * WAVE + threadIdx.x;
   if (s >= g.n_streams) return;
+  // (race hunt, $RNNOISE_AMD_HP_AB: 256 = drain the wave's stores before the pitch ring is read back, 512 = raised issue
+  //  priority, 1024 = drain the tap stores before the wave ends)
+  if (mode & 512) __builtin_amdgcn_s_setprio(3);
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
@@ -83,6 +90,10 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
   // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
   // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
+  if (mode & 256) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
   {
     const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
     const int ring0 = RN_RING0(slot);
@@ -144,9 +155,14 @@ rn_hp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
 #pragma unroll
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
     }
+    if (mode & 1024) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
   }
 }
 
+#ifndef RN_HP_VARIANT_ONLY
 // ---------------------------------------------------------------------------------------------
 // K0 for a handful of streams (the one-stream states behind rnnoise_process_frame, and batches of up to 64 streams): the
 // same arithmetic with ONE WAVE PER STREAM instead of one lane, arranged for latency.  What is serial stays serial -- the
@@ -295,14 +311,25 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 // (up to RN_HP_ONE_MAX streams one wave per stream is the faster form -- measured K0 at 256 / 1024 / 2048 / 4096 streams: 24 / 26 / 35 / 66 us
 // against 55 / 55 / 55 / 59 us lane = stream: its 12.5 KB of LDS per wave limit a CU to 12 waves)
 #define RN_HP_ONE_MAX 3072
+#if RN_INSTRUMENT
+extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
+#else
+#define rn_hp_slp_kernel rn_hp_kernel
+#endif
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
   static const int one_max = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : RN_HP_ONE_MAX; }();  // (A/B runs)
   if (g->n_streams <= one_max) {
     RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16, RnRows{});
     return hipGetLastError();
   }
-  RN_LAUNCH(rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot,
-            1 | (in_s16 ? 2 : 0));
+  static const int ab = [] { const char *e = getenv("RNNOISE_AMD_HP_AB"); return e ? atoi(e) & (256 | 512 | 1024) : 0; }();  // (A/B runs)
+#if RN_INSTRUMENT
+  static const bool slp = [] { const char *e = getenv("RNNOISE_AMD_HP_AB"); return e && (atoi(e) & 2048); }();  // (A/B: hp_slp.hip)
+#else
+  const bool slp = false;
+#endif
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g,
+            static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
@@ -315,3 +342,4 @@ extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *g, const RnRows *rows,
   hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), taps_here, 0, *rows);
   return hipGetLastError();
 }
+#endif  // RN_HP_VARIANT_ONLY

@@ -12,7 +12,9 @@
 // once the next layer's input and this layer's recurrent operand of the next frame -- leaves the same way.
 // Arithmetic per element is the fused kernel's, so the bits are too (tests/test_gpu_parity.py runs both; tools/ab_layers.py).
 #include "nn_common.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define GM 4  // 16-stream tiles per workgroup
 #ifndef GW
@@ -20,14 +22,20 @@
 #endif
 #define GTHREADS (64 * GW)
 
-struct GruLds {
+// W: waves per GRU workgroup, HB: f32 row buffers per wave.  The shipping kernel is <8, 3>: one buffer per unit tile of a wave,
+// every buffer written once per launch.  <4, 1> (one wave per SIMD, 72 KB: two workgroups per CU, or one beside analysis
+// workgroups of the next frame) is the round-4 variant that was not bit-stable in the pipelined schedule; it and the other
+// instantiations below are kept as A/B variants ($RNNOISE_AMD_GRU_VARIANT; profiles/r5_gru_race.txt names what went wrong).
+template <int W, int HB>
+struct GruLdsT {
   uint16_t lut[4096];            // rcpps table (rn_dev.h: rcp16)
   int8_t xq[GM][KT * 64 * 16];   // layer input images
   int8_t hq[GM][KT * 64 * 16];   // recurrent state images
-  float hrow[GW][24 / GW][GM * TS][16];  // per wave and unit tile: the f32 state of its 16 units for the workgroup's 64 streams
-                                         // (the blend z*h + (1-z)*candidate needs them exact)
+  float hrow[W][HB][GM * TS][16];  // per wave (and unit tile, HB == 24 / W): the f32 state of its 16 units for the workgroup's
+                                   // 64 streams (the blend z*h + (1-z)*candidate needs them exact)
 };
-static_assert(sizeof(GruLds) <= 160 * 1024, "one workgroup per CU, all of its LDS");
+static_assert(sizeof(GruLdsT<8, 3>) <= 160 * 1024, "one workgroup per CU, all of its LDS");
+static_assert(sizeof(GruLdsT<4, 1>) <= 80 * 1024, "two workgroups per CU");
 
 // Addressing in the GRU kernel is (uniform base, unsigned 32-bit BYTE offset): one VGPR per address instead of a 64-bit
 // pair per pointer (rn_launch_nn_layers refuses batches whose state plane exceeds 4 GB)
@@ -196,10 +204,25 @@ __device__ __forceinline__ void int8_gates(v4i acc[3][GM], AFrags<AD> &A, int s0
   }
 }
 
-template <int AD>
+#if RN_INSTRUMENT
+// CHK instantiations (tools/gru_race.py): every h_old vector a lane takes from its LDS row buffer is compared with the same 16
+// bytes loaded straight from HBM.  [0] = mismatching vectors seen, [1] = of them equal to the PREVIOUS unit tile's vector of that
+// lane (stale buffer: the LDS-DMA had not landed), [2] = vectors checked (low 32 bits); then up to 40 records of 12 words:
+// block | wave, ui, t, lane | got[4] | want[4] | previous tile's[2].  [3] = words of the LDS images (layer input, recurrent state,
+// rcpps table) that differed from HBM behind the prologue's barrier or (input image, table) at the end of the kernel; their
+// records: block | 0xffff0000 + 0x100 * (0 start, 1 end) + region (0..3 xq, 4..7 hq, 8 table) | word | got | want | wave
+__device__ unsigned rn_gru_race_log[4 + 40 * 12];
+#endif
+// layer_arg: bits 0-1 layer; bit 2: activations element by element (A/B); bits 3-4: what stands between the wait for this wave's
+// row DMA and its reads of those rows, beyond s_waitcnt vmcnt(0) -- 0 nothing, 1 = lgkmcnt(0) + s_sleep (256 clocks), 2 = a
+// workgroup barrier, 3 = lgkmcnt(0) + buffer_inv-free s_nop ladder (A/B runs of the race hunt only)
+template <int AD, int W, int HB, bool CHK, bool DMA = true>
 __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer_arg) {
+  typedef GruLdsT<W, HB> GruLds;
+  static_assert(24 % W == 0 && (HB == 24 / W || HB <= 2), "unit tiles per wave; row buffers");
   const int layer = layer_arg & 3;
   const bool batched_act = !(layer_arg & 4);
+  const int settle = (layer_arg >> 3) & 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
@@ -227,33 +250,67 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   // Prologue: the two images of the workgroup's GM tiles and the rcpps table go straight from HBM to LDS (1 KB per wave
   // instruction, no staging registers, no ds_write pass: the images are stored in exactly the order LDS wants), then
   // this wave's f32 rows for its first unit tile.
-  auto rows_fetch = [&](int ui) {  // f32 state of units 16 u .. 16 u + 15, u = wave + GW ui, of the 64 streams: 4 pieces
-    const int u = wave + GW * ui;
+  // (DMA == false, A/B variant "w4nodma": the same pieces through registers and ds_write_b128)
+  auto piece = [&](const void *gsrc, const void *lds_base, unsigned off) {
+    if (DMA) dma_1k(gsrc, lds_addr(lds_base) + off);
+    else *reinterpret_cast<v4i *>(const_cast<char *>(static_cast<const char *>(lds_base)) + off + lane * 16) = *static_cast<const v4i *>(gsrc);
+  };
+  auto row_buf = [&](int ui) { return HB == 24 / W ? ui : ui % HB; };
+  auto rows_fetch = [&](int ui) {  // f32 state of units 16 u .. 16 u + 15, u = wave + W ui, of the 64 streams: 4 pieces
+    const int u = wave + W * ui;
 #pragma unroll
     for (int i = 0; i < GM * TS * 16 * 4 / 1024; i++) {
       const int idx = i * 64 + lane, row = idx >> 2, seg = idx & 3, s = tile0 * TS + row, sc = s < N ? s : N - 1;
-      dma_1k(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), lds_addr(&L.hrow[wave][ui][0][0]) + i * 1024);
+      piece(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), &L.hrow[wave][row_buf(ui)][0][0], i * 1024);
     }
   };
   {
     constexpr int NCHUNK = 2 * GM * KT;  // 1 KB pieces
 #pragma unroll
-    for (int j = 0; j < (NCHUNK + GW - 1) / GW; j++) {
-      const int c = wave + j * GW;  // wave-uniform
+    for (int j = 0; j < (NCHUNK + W - 1) / W; j++) {
+      const int c = wave + j * W;  // wave-uniform
       if (c < NCHUNK) {
         const int which = c / (GM * KT), cc = c - which * (GM * KT), t = cc / KT, kt = cc - t * KT;
         const int tile = (tile0 + t < n_tiles) ? tile0 + t : n_tiles - 1;
-        dma_1k((which ? himg : xin) + ((size_t)tile * (KT * 64 * 16) + kt * 1024 + lane * 16), lds_addr(which ? L.hq[t] : L.xq[t]) + kt * 1024);
+        piece((which ? himg : xin) + ((size_t)tile * (KT * 64 * 16) + kt * 1024 + lane * 16), which ? L.hq[t] : L.xq[t], kt * 1024);
       }
     }
-    static_assert(GW >= 8, "the LUT is 8 pieces");
-    if (wave < 8) dma_1k(reinterpret_cast<const uint32_t *>(tb.rcp16) + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
+#pragma unroll
+    for (int c = wave; c < 8; c += W)  // the LUT is 8 pieces
+      piece(reinterpret_cast<const uint32_t *>(tb.rcp16) + c * 256 + lane * 4, L.lut, c * 1024);
     rows_fetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   const unsigned long long clk1 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
   __builtin_amdgcn_s_barrier();
   const unsigned long long clk2 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
+#if RN_INSTRUMENT
+  auto image_check = [&](int when) {
+    auto cmp = [&](const void *lds, const void *hbm, int words, int region) {
+      for (int w = tid; w < words; w += 64 * W) {
+        const unsigned got = reinterpret_cast<const unsigned *>(lds)[w], want = reinterpret_cast<const unsigned *>(hbm)[w];
+        if (got != want) {
+          atomicAdd(&rn_gru_race_log[3], 1u);
+          const unsigned k = atomicAdd(&rn_gru_race_log[0], 1u);
+          if (k < 40) {
+            unsigned *rec = rn_gru_race_log + 4 + 12 * k;
+            rec[0] = blockIdx.x; rec[1] = 0xffff0000u + 0x100u * when + region; rec[2] = w; rec[3] = got; rec[4] = want; rec[5] = wave;
+          }
+        }
+      }
+    };
+    for (int t = 0; t < GM; t++) {
+      const int tile = (tile0 + t < n_tiles) ? tile0 + t : n_tiles - 1;
+      cmp(L.xq[t], xin + (size_t)tile * (KT * 64 * 16), KT * 64 * 4, t);
+      if (when == 0) cmp(L.hq[t], himg + (size_t)tile * (KT * 64 * 16), KT * 64 * 4, 4 + t);
+    }
+    cmp(L.lut, tb.rcp16, 2048, 8);
+  };
+  if (CHK) {
+    image_check(0);
+    __builtin_amdgcn_s_barrier();  // (nobody rewrites its tiles' state image before everybody has compared it)
+  }
+#endif
 
 #pragma unroll
   for (int t = 0; t < GM; t++) live[t] = (tile0 + t) * TS + n < N && !sil[t];  // silent streams keep their state (src/denoise.c:474)
@@ -261,15 +318,16 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   // The two waves of a SIMD run the same phases from the same barrier: left alone they want the MFMA pipe together and
   // the VALU together.  Giving one of them issue priority lets it run ahead, after which one's MFMA block overlaps the
   // other's epilogue.
-  if (wave < GW / 2) __builtin_amdgcn_s_setprio(2);
+  if (wave < W / 2 && !(layer_arg & 32)) __builtin_amdgcn_s_setprio(2);  // (bit 5: $RNNOISE_AMD_GRU_PRIO=0, A/B runs)
+  [[maybe_unused]] v4f h_prev[GM] = {};
 #pragma unroll 1
-  for (int ui = 0; ui < 24 / GW; ui++) {
-    const int u = wave + GW * ui, unit0 = 16 * u + 4 * gq;
+  for (int ui = 0; ui < 24 / W; ui++) {
+    const int u = wave + W * ui, unit0 = 16 * u + 4 * gq;
     // (instrumented build, layer 0, wave 0: shader-clock deltas inside a unit tile -> slots 1376 + 5 ui + {0: input gates, 1: their
     //  conversion, 2: recurrent gates, 3: wait + rows + conversion, 4: activations and stores}; tools/k1_cycles.py --layers)
 #if RN_INSTRUMENT
     unsigned long long tc = (dbg && layer == 0) ? __builtin_amdgcn_s_memtime() : 0;
-#define GRU_TAP(i) do { if (dbg && layer == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg[1376 - (RN_DBG_CLK2 + 7) + 5 * ui + (i)] = (float)(n_ - tc); tc = n_; } } while (0)
+#define GRU_TAP(i) do { if (dbg && layer == 0 && ui < 3) {  /* (three unit tiles' worth of slots: the four-wave variants have six) */ const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg[1376 - (RN_DBG_CLK2 + 7) + 5 * ui + (i)] = (float)(n_ - tc); tc = n_; } } while (0)
 #else
 #define GRU_TAP(i) do { } while (0)
 #endif
@@ -306,9 +364,44 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     GRU_TAP(2);
     // all of this wave's loads have landed (the last A fragment was just used): its f32 rows for this tile are in LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (settle == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_sleep 4" ::: "memory");
+    else if (settle == 2) __builtin_amdgcn_s_barrier();
+    else if (settle == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][ui][TS * t + n][4 * gq]);
+    for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][row_buf(ui)][TS * t + n][4 * gq]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if RN_INSTRUMENT
+    if (CHK) {
+#pragma unroll
+      for (int t = 0; t < GM; t++) {
+        const v4f want = ldg<v4f>(st, (unsigned)(sn[t] * RN_GRU + unit0) * 4u);
+        bool bad = false, stale = true;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          bad |= __float_as_uint(want[r]) != __float_as_uint(h_old[t][r]);
+          stale &= __float_as_uint(h_prev[t][r]) == __float_as_uint(h_old[t][r]);
+        }
+        atomicAdd(&rn_gru_race_log[2], 1u);
+        if (bad) {
+          const unsigned k = atomicAdd(&rn_gru_race_log[0], 1u);
+          if (stale && ui > 0) atomicAdd(&rn_gru_race_log[1], 1u);
+          if (k < 40) {
+            unsigned *rec = rn_gru_race_log + 4 + 12 * k;
+            rec[0] = blockIdx.x;
+            rec[1] = (unsigned)wave | (unsigned)ui << 8 | (unsigned)t << 16 | (unsigned)lane << 24;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              rec[2 + r] = __float_as_uint(h_old[t][r]);
+              rec[6 + r] = __float_as_uint(want[r]);
+            }
+            rec[10] = __float_as_uint(h_prev[t][0]);
+            rec[11] = __float_as_uint(h_prev[t][1]) ;
+          }
+        }
+        h_prev[t] = h_old[t];
+      }
+    }
+#endif
     v4f gr[3][GM];
 #pragma unroll
     for (int gate = 0; gate < 3; gate++) {
@@ -328,7 +421,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     // vmcnt retires in order, so any load issued behind them (the constants above, the next A fragments) waits them out.
     __builtin_amdgcn_sched_barrier(0);
     GRU_TAP(3);
-    if (u + GW < 24) rows_fetch(ui + 1);
+    if (u + W < 24) rows_fetch(ui + 1);
     __builtin_amdgcn_sched_barrier(0);
     // one tile's 4 rows at a time: eight sigmoid lookups in flight, then four tanh lookups ($RNNOISE_AMD_GRU_ACT=0 at launch:
     // element by element, as before -- A/B runs)
@@ -377,6 +470,9 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     GRU_TAP(4);
 #undef GRU_TAP
   }
+#if RN_INSTRUMENT
+  if (CHK) image_check(1);
+#endif
   if (dbg && tile0 * TS < N) {
     const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
     dbg[0] = (float)(clk1 - clk0);
@@ -384,26 +480,90 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     dbg[2] = (float)(clk3 - clk2);
   }
 }
-extern "C" __global__ void __launch_bounds__(GTHREADS) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  gru_body<2>(g, m, tb, layer);
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 3, false>(g, m, tb, layer);
 }
+// A/B variants (not taken by default): see GruLdsT
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+rn_nn_gru_w4_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 4, 1, false>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+rn_nn_gru_w4b2_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 4, 2, false>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+rn_nn_gru_w4nodma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 4, 1, false, false>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_w8b1_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 1, false>(g, m, tb, layer);
+}
+#if RN_INSTRUMENT
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+rn_nn_gru_w4_chk_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 4, 1, true>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_w8b1_chk_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 1, true>(g, m, tb, layer);
+}
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_chk_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 3, true>(g, m, tb, layer);
+}
+// copies the race log to the host and clears it
+extern "C" hipError_t rn_gru_race_log_read(unsigned *out, int words) {
+  const size_t n = sizeof(rn_gru_race_log);
+  if ((size_t)words * 4 < n) return hipErrorInvalidValue;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rn_gru_race_log), n);
+  static const unsigned zero[sizeof(rn_gru_race_log) / 4] = {};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(rn_gru_race_log), zero, n);
+  return e;
+}
+#endif
 
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
                                              hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS;
+  typedef void (*Kernel)(RnGroupDev, RnModelDev, RnTablesDev, int);
+  struct Variant { const char *name; Kernel k; int threads; size_t lds; };
+  static const Variant variants[] = {
+      {"w8", rn_nn_gru_kernel, 512, sizeof(GruLdsT<8, 3>)},          {"w4", rn_nn_gru_w4_kernel, 256, sizeof(GruLdsT<4, 1>)},
+      {"w4b2", rn_nn_gru_w4b2_kernel, 256, sizeof(GruLdsT<4, 2>)},   {"w8b1", rn_nn_gru_w8b1_kernel, 512, sizeof(GruLdsT<8, 1>)},
+      {"w4nodma", rn_nn_gru_w4nodma_kernel, 256, sizeof(GruLdsT<4, 1>)},  // no LDS-DMA: pieces through registers
+      {"w4big", rn_nn_gru_w4_kernel, 256, sizeof(GruLdsT<8, 3>)},  // the w4 kernel asking for a whole CU's LDS: one workgroup per CU
+#if RN_INSTRUMENT
+      {"w4chk", rn_nn_gru_w4_chk_kernel, 256, sizeof(GruLdsT<4, 1>)}, {"w8b1chk", rn_nn_gru_w8b1_chk_kernel, 512, sizeof(GruLdsT<8, 1>)},
+      {"w8chk", rn_nn_gru_chk_kernel, 512, sizeof(GruLdsT<8, 3>)},
+#endif
+  };
+  constexpr int NV = sizeof(variants) / sizeof(variants[0]);
+  // $RNNOISE_AMD_GRU_VARIANT (A/B runs; an unknown name is an error, not a silent default)
+  static const int vi = [] {
+    const char *e = getenv("RNNOISE_AMD_GRU_VARIANT");
+    if (!e || !*e) return 0;
+    for (int i = 0; i < NV; i++)
+      if (!strcmp(e, variants[i].name)) return i;
+    fprintf(stderr, "[rnnoise_amd] RNNOISE_AMD_GRU_VARIANT=%s: no such variant in this build\n", e);
+    return -1;
+  }();
+  if (vi < 0) return hipErrorInvalidValue;
+  const Variant &v = variants[vi];
   // more than 64 KB of LDS is an opt-in, per device (a process may hold batches on several GPUs)
   static bool opted[64] = {};
-  auto kernel = rn_nn_gru_kernel;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!opted[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GruLds));
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
     if (attr != hipSuccess) return attr;
     opted[dev] = true;
   }
-  static const int act_flag = [] { const char *e = getenv("RNNOISE_AMD_GRU_ACT"); return (e && atoi(e) == 0) ? 4 : 0; }();
-  RN_LAUNCH(kernel, dim3((n_tiles + GM - 1) / GM), dim3(GTHREADS), sizeof(GruLds), st, e0, e1, *g, *m, *tb, layer | act_flag);
+  // bit 2: $RNNOISE_AMD_GRU_ACT=0; bits 3-4: $RNNOISE_AMD_GRU_SETTLE (gru_body)
+  static const int flags = [] {
+    const char *e = getenv("RNNOISE_AMD_GRU_ACT"), *s = getenv("RNNOISE_AMD_GRU_SETTLE"), *p = getenv("RNNOISE_AMD_GRU_PRIO");
+    return ((e && atoi(e) == 0) ? 4 : 0) | ((s ? atoi(s) & 3 : 0) << 3) | ((p && atoi(p) == 0) ? 32 : 0);
+  }();
+  RN_LAUNCH(v.k, dim3((n_tiles + GM - 1) / GM), dim3(v.threads), v.lds, st, e0, e1, *g, *m, *tb, layer | flags);
   return hipGetLastError();
 }
 

@@ -1,0 +1,300 @@
+// pk_coissue_probe.hip -- developer probe (not part of the library): do packed-FP32 VALU instructions of one wave keep their
+// bits while ANOTHER wave on the same SIMD issues matrix instructions?
+//
+// Background (profiles/r5_gru_race.txt): the lane = stream high-pass kernel K0 (hp_kernel.hip), compiled with the SLP vectoriser
+// (v_pk_mul_f32 / v_pk_add_f32 in its autocorrelation chains, many of them with op_sel / op_sel_hi operand selects), returned a
+// wrong sum in lanes 48..63 of some waves whenever waves of the four-wave GRU layer kernel (back-to-back
+// v_mfma_i32_16x16x64_i8) shared its SIMDs -- and never once it was built without packed math.  This probe takes the two
+// kernels out of the picture: a VICTIM wave runs a chain of one packed form on operands that are the same in all 64 lanes
+// (so every lane must end with lane 0's bits, and with the bits a scalar v_mul_f32 / v_add_f32 chain gives), an AGGRESSOR
+// wave runs one instruction class flat out.  Two placements:
+//   one kernel:   workgroups of 8 waves = 2 per SIMD, waves 0-3 aggressors, 4-7 victims (or alternating: --roles 0)
+//   two kernels:  aggressor workgroups (4 waves, 230 VGPRs, 72 KB of LDS: two per CU like the w4 layer kernel) on one
+//                 stream, one-wave victim workgroups (~100 VGPRs, no LDS) on another, as K0 meets the layer kernel
+// Output: per (victim form, aggressor) the number of victim waves with a wrong lane, the lanes by quarter, the component.
+//
+//   build: make -C rnnoise_amd/csrc tools ; run: rnnoise_amd/csrc/build/pk_coissue_probe [--iters 4000] [--two 1] [--roles 2]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+enum Victim { V_SCALAR, V_PK_PLAIN, V_PK_SELHI, V_PK_SEL, V_PK_FMA, V_PK_MOV, V_F64, V_PK_SEL0, V_PK_ADDSEL, V_PK_FMASEL, V_PK_SWAP, NV };
+static const char *VN[] = {"v_mul_f32 + v_add_f32 (control)", "v_pk_mul_f32 + v_pk_add_f32", "v_pk_mul_f32 op_sel_hi:[1,0] + v_pk_add_f32",
+                           "v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32", "v_pk_fma_f32", "v_pk_mov_b32 op_sel:[1,0] + v_pk_add_f32", "v_fma_f64",
+                           "v_pk_mul_f32 op_sel:[1,0] + v_pk_add_f32", "v_pk_mul_f32 + v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
+                           "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] + v_pk_add_f32"};
+enum Aggressor { A_IDLE, A_MFMA_I8, A_MFMA_F32, A_VALU, A_PK, A_F64, A_LDS, A_MFMA_I8_CHAIN, A_MFMA_I8_BURST, A_MFMA_F32_IND, A_MFMA_BF16, A_MFMA_I8_32, NA };
+static const char *AN[] = {"idle (s_sleep)", "v_mfma_i32_16x16x64_i8 x12 independent", "v_mfma_f32_16x16x4_f32 chain", "v_fma_f32 flood", "v_pk_fma_f32 flood",
+                           "v_fma_f64 flood", "ds_read_b128 flood", "v_mfma_i32_16x16x64_i8 dependent chain", "6 x v_mfma_i32_16x16x64_i8, then ~200 clocks of VALU",
+                           "v_mfma_f32_16x16x4_f32 x12 independent", "v_mfma_f32_16x16x32_bf16 x12 independent", "v_mfma_i32_32x32x32_i8 x4 independent"};
+
+// The victim's chain: x_t from a small LCG (the same in every lane), w = the previous two x; per step two products and two
+// sums, as a lag pair of K0's autocorrelation.  Returns (acc.x, acc.y).  `form` selects how the two products / sums are issued.
+__device__ __forceinline__ float lcg(unsigned &s) {
+  s = s * 1664525u + 1013904223u;
+  return (float)(int)(s >> 9) * (1.f / 4194304.f) - 1.f;
+}
+template <int FORM>
+__device__ __forceinline__ v2f victim_chain(int iters, unsigned seed) {
+  v2f acc = {0.f, 0.f}, w = {0.f, 0.f};
+  double dacc = 0;
+  unsigned s = seed;
+  for (int i = 0; i < iters; i++) {
+    const float x0 = lcg(s);
+    v2f x = {x0, 0.f}, p;
+    if (FORM == V_SCALAR) {
+      float p0, p1;
+      asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(p0), "=&v"(p1) : "v"(w.x), "v"(w.y), "v"(x0));
+      asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(acc.x), "+v"(acc.y) : "v"(p0), "v"(p1));
+    } else if (FORM == V_PK_PLAIN) {
+      x.y = x0;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_SELHI) {  // both halves of src1 from its low dword
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_SEL) {  // src1 = (hi, hi): put x0 in the high dword
+      x = v2f{0.f, x0};
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_FMA) {  // (fused: compared lane against lane only)
+      x.y = x0;
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    } else if (FORM == V_PK_MOV) {  // p = (w.y, x0) by v_pk_mov_b32, then a packed add
+      x.y = x0;
+      asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_SEL0) {  // src0 = (hi, hi): the products are (w.y x0, w.y x0)
+      x.y = x0;
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_ADDSEL) {  // the select on the packed add: acc += (p.y, p.y)
+      x.y = x0;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_FMASEL) {
+      x = v2f{0.f, x0};
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(w), "v"(x));
+    } else if (FORM == V_PK_SWAP) {  // src1 swapped: (w.x x.y, w.y x.x)
+      x = v2f{.5f * x0, x0};
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else {  // V_F64
+      const double xd = (double)x0, wd = (double)w.x;
+      asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(dacc) : "v"(wd), "v"(xd));
+    }
+    w.y = w.x;
+    w.x = x0;
+  }
+  if (FORM == V_F64) return v2f{__uint_as_float((unsigned)__double_as_longlong(dacc)), __uint_as_float((unsigned)(__double_as_longlong(dacc) >> 32))};
+  return acc;
+}
+__device__ __forceinline__ v2f victim_run(int form, int iters, unsigned seed) {
+  switch (form) {
+    case V_SCALAR: return victim_chain<V_SCALAR>(iters, seed);
+    case V_PK_PLAIN: return victim_chain<V_PK_PLAIN>(iters, seed);
+    case V_PK_SELHI: return victim_chain<V_PK_SELHI>(iters, seed);
+    case V_PK_SEL: return victim_chain<V_PK_SEL>(iters, seed);
+    case V_PK_FMA: return victim_chain<V_PK_FMA>(iters, seed);
+    case V_PK_MOV: return victim_chain<V_PK_MOV>(iters, seed);
+    case V_PK_SEL0: return victim_chain<V_PK_SEL0>(iters, seed);
+    case V_PK_ADDSEL: return victim_chain<V_PK_ADDSEL>(iters, seed);
+    case V_PK_FMASEL: return victim_chain<V_PK_FMASEL>(iters, seed);
+    case V_PK_SWAP: return victim_chain<V_PK_SWAP>(iters, seed);
+    default: return victim_chain<V_F64>(iters, seed);
+  }
+}
+// out[0] waves checked, out[1] waves with a wrong lane, out[2..5] wrong lanes by quarter, out[6] wrong .x, out[7] wrong .y,
+// out[8..11]: first bad record (wave id, lane, got bits, want bits)
+__device__ __forceinline__ void victim_check(v2f r, unsigned *out, int wave_id) {
+  const int lane = threadIdx.x & 63;
+  const unsigned rx = __float_as_uint(r.x), ry = __float_as_uint(r.y);
+  const unsigned wx = __builtin_amdgcn_readfirstlane(rx), wy = __builtin_amdgcn_readfirstlane(ry);  // lane 0's
+  const bool bx = rx != wx, by = ry != wy;
+  const unsigned long long mask = __ballot(bx || by);
+  if (lane == 0) {
+    atomicAdd(&out[0], 1u);
+    if (mask) atomicAdd(&out[1], 1u);
+  }
+  if (bx || by) {
+    atomicAdd(&out[2 + (lane >> 4)], 1u);
+    if (bx) atomicAdd(&out[6], 1u);
+    if (by) atomicAdd(&out[7], 1u);
+    if (atomicCAS(&out[8], 0u, (unsigned)wave_id + 1u) == 0u) {
+      out[9] = lane;
+      out[10] = bx ? rx : ry;
+      out[11] = bx ? wx : wy;
+    }
+  }
+}
+
+__device__ __forceinline__ float aggressor_run(int kind, int iters, const float *lds) {
+  const int lane = threadIdx.x & 63;
+  float sink = 0;
+  if (kind == A_IDLE) {
+    for (int i = 0; i < iters; i++) __builtin_amdgcn_s_sleep(8);
+  } else if (kind == A_MFMA_I8) {
+    v4i acc[12];
+    for (int k = 0; k < 12; k++) acc[k] = v4i{lane, k, 0, 0};
+    const v4i a = {lane * 3, 7, lane, 1}, b = {lane, 5, 9, lane * 7};
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[k], 0, 0, 0);
+    }
+    for (int k = 0; k < 12; k++) sink += (float)(acc[k][0] ^ acc[k][1] ^ acc[k][2] ^ acc[k][3]);
+  } else if (kind == A_MFMA_I8_CHAIN) {
+    v4i acc = {lane, 0, 0, 0};
+    const v4i a = {lane * 3, 7, lane, 1}, b = {lane, 5, 9, lane * 7};
+    for (int i = 0; i < 12 * iters; i++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+    sink = (float)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+  } else if (kind == A_MFMA_I8_BURST) {
+    v4i acc[6];
+    float f = lane;
+    for (int k = 0; k < 6; k++) acc[k] = v4i{lane, k, 0, 0};
+    const v4i a = {lane * 3, 7, lane, 1}, b = {lane, 5, 9, lane * 7};
+    for (int i = 0; i < 2 * iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[k], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 48; k++) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f) : "v"(1e-7f));
+    }
+    for (int k = 0; k < 6; k++) sink += (float)(acc[k][0] ^ acc[k][1] ^ acc[k][2] ^ acc[k][3]);
+    sink += f;
+  } else if (kind == A_MFMA_F32_IND) {
+    v4f acc[12];
+    for (int k = 0; k < 12; k++) acc[k] = v4f{(float)lane, (float)k, 0, 0};
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)lane, 1e-3f, acc[k], 0, 0, 0);
+    }
+    for (int k = 0; k < 12; k++) sink += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  } else if (kind == A_MFMA_BF16) {
+    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+    v4f acc[12];
+    for (int k = 0; k < 12; k++) acc[k] = v4f{(float)lane, (float)k, 0, 0};
+    v8bf a, b;
+    for (int e = 0; e < 8; e++) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)1e-3f; }
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    for (int k = 0; k < 12; k++) sink += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  } else if (kind == A_MFMA_I8_32) {
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    v16i acc[4];
+    for (int k = 0; k < 4; k++) for (int e = 0; e < 16; e++) acc[k][e] = lane + k + e;
+    const v4i a = {lane * 3, 7, lane, 1}, b = {lane, 5, 9, lane * 7};
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[k], 0, 0, 0);
+    }
+    for (int k = 0; k < 4; k++) for (int e = 0; e < 16; e++) sink += (float)acc[k][e];
+  } else if (kind == A_MFMA_F32) {
+    v4f acc = {0, 0, 0, 0};
+    for (int i = 0; i < 4 * iters; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)lane, 1e-3f, acc, 0, 0, 0);
+    sink = acc[0] + acc[1] + acc[2] + acc[3];
+  } else if (kind == A_VALU || kind == A_PK || kind == A_F64) {
+    float f[8];
+    v2f p[8];
+    double d[8];
+    for (int k = 0; k < 8; k++) { f[k] = lane + k; p[k] = v2f{(float)lane, (float)k}; d[k] = lane * k; }
+    for (int i = 0; i < 4 * iters; i++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (kind == A_VALU) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f[k]) : "v"(1e-7f));
+        else if (kind == A_PK) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[k]) : "v"(v2f{1e-7f, 1e-7f}));
+        else asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[k]) : "v"(1e-7));
+      }
+    }
+    for (int k = 0; k < 8; k++) sink += f[k] + p[k].x + p[k].y + (float)d[k];
+  } else {  // A_LDS
+    v4f a = {0, 0, 0, 0};
+    for (int i = 0; i < 8 * iters; i++) a += *reinterpret_cast<const v4f *>(lds + ((lane * 4 + i * 256) & 4095));
+    sink = a[0] + a[1] + a[2] + a[3];
+  }
+  return sink;
+}
+
+// one kernel: 8 waves per workgroup, role by wave index
+extern "C" __global__ void __launch_bounds__(512) probe_one(int form, int kind, int v_iters, int a_iters, int role_shift, unsigned *out, float *sink) {
+  extern __shared__ float lds[];
+  for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = i;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  if ((wave >> role_shift) & 1) {
+    victim_check(victim_run(form, v_iters, 12345u), out, blockIdx.x * 8 + wave);
+  } else {
+    const float s = aggressor_run(kind, a_iters, lds);
+    if (s == 1.2345f) sink[0] = s;
+  }
+}
+// two kernels: the aggressor as the w4 layer kernel meets K0 (4 waves, >= 224 VGPRs so that one wave owns half a SIMD's file)
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) probe_aggressor(int kind, int a_iters, float *sink) {
+  extern __shared__ float lds[];
+  for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i;
+  __syncthreads();
+  asm volatile("v_mov_b32 v229, 0" ::: "v229");  // (claims the register budget of the layer kernel)
+  const float s = aggressor_run(kind, a_iters, lds);
+  if (s == 1.2345f) sink[0] = s;
+}
+extern "C" __global__ void __launch_bounds__(64) probe_victim(int form, int v_iters, unsigned *out) {
+  asm volatile("v_mov_b32 v100, 0" ::: "v100");
+  victim_check(victim_run(form, v_iters, 12345u), out, blockIdx.x);
+}
+
+#define OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+int main(int argc, char **argv) {
+  int iters = 4000, two = 1, roles = 2, reps = 3;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--two")) two = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--roles")) roles = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[i + 1]);
+  }
+  unsigned *d_out;
+  float *d_sink;
+  OK(hipMalloc(&d_out, 64));
+  OK(hipMalloc(&d_sink, 64));
+  hipStream_t sa, sv;
+  OK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+  OK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+  OK(hipFuncSetAttribute(reinterpret_cast<const void *>(probe_aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+  hipDeviceProp_t prop;
+  OK(hipGetDeviceProperties(&prop, 0));
+  printf("# pk_coissue_probe on %s: victim chains of %d steps, %s, %d launches per cell\n", prop.gcnArchName, iters,
+         two ? "two kernels (aggressor: 4-wave workgroups, 230 VGPRs, 72 KB LDS; victim: one-wave workgroups)" : "one kernel (8 waves, 2 per SIMD)", reps);
+  printf("# cell = victim waves with a wrong lane / waves checked [wrong lanes in quarters 0..3 | wrong .x, .y]\n");
+  for (int form = 0; form < NV; form++) {
+    printf("%s\n", VN[form]);
+    for (int kind = 0; kind < NA; kind++) {
+      unsigned tot[12] = {};
+      for (int r = 0; r < reps; r++) {
+        OK(hipMemset(d_out, 0, 64));
+        OK(hipDeviceSynchronize());
+        if (two) {
+          // aggressors first (they run ~10x longer than one victim wave), victims stream in beside them
+          hipLaunchKernelGGL(probe_aggressor, dim3(512), dim3(256), 72 * 1024, sa, kind, iters * 6, d_sink);
+          hipLaunchKernelGGL(probe_victim, dim3(8192), dim3(64), 0, sv, form, iters, d_out);
+        } else {
+          hipLaunchKernelGGL(probe_one, dim3(1024), dim3(512), 16384, sv, form, kind, iters, iters / 2, roles, d_out, d_sink);
+        }
+        OK(hipDeviceSynchronize());
+        unsigned h[16];
+        OK(hipMemcpy(h, d_out, 64, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) tot[k] += h[k];
+        if (h[8] && !tot[8]) for (int k = 8; k < 12; k++) tot[k] = h[k];
+      }
+      printf("    beside %-42s %6u / %-7u [%u %u %u %u | %u %u]", AN[kind], tot[1], tot[0], tot[2], tot[3], tot[4], tot[5], tot[6], tot[7]);
+      if (tot[8]) printf("  first: wave %u lane %u got %08x want %08x", tot[8] - 1, tot[9], tot[10], tot[11]);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
+  return 0;
+}

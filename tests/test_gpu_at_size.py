@@ -81,6 +81,59 @@ def test_16384_streams_on_the_host_profile(blob_default):
     _tiled_check(blob_default, 16384, (3, 4), silent_stream=5)
 
 
+def _soak(blob, N, reps, cycles):
+    """The pipelined schedule for a long time: `reps` runs from reset of `cycles` x 24 frames each, as calls of 8 + 5 + 1 + 8 + 2
+    frames over a 24-frame input that repeats (what fits in HBM at 65,536 streams), N/32 replicas of a 32-stream block.  After
+    EVERY call every replica's pcm / gains / vad is compared with replica 0 on the GPU; replica 0's block is collected and, at the
+    end of a run, compared frame by frame with one oracle run of the whole sequence, as is the state of streams from three
+    places of the batch.  This is the test that would have seen round 4's "one run in ten" corruption in the product's own
+    configuration (profiles/r5_gru_race.txt): a wrong bit anywhere in ~10^8 stream-frames fails it."""
+    import torch
+    calls, P = (8, 5, 1, 8, 2), 24
+    T = cycles * P
+    base = synth.batch_pcm(range(32), P)
+    base[:3, 9] = 0                                   # a stream that is silent whenever the input wraps ...
+    base[P - 5:P - 3, 12] = 0                         # ... and one that goes silent inside a call
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(base).to(dev).repeat(1, N // 32, 1).contiguous()
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty((P, N), device=dev)
+    d_gains = torch.empty((P, N, 32), device=dev)
+    m = capi.Model(blob)
+    b = capi.Batch(m, N)
+    assert b.set_nn_path(1) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    want = oracle_run(blob, np.concatenate([base] * cycles))
+    for rep in range(reps):
+        b.reset()
+        got = {"out": [], "gains": [], "vad": []}
+        for c in range(cycles):
+            f = 0
+            for n in calls:
+                b.process_device(d_out[f].data_ptr(), d_in[f].data_ptr(), d_vad[f].data_ptr(), d_gains[f].data_ptr(), n, st)
+                for name, t, w in (("out", d_out, 480), ("gains", d_gains, 32), ("vad", d_vad, 1)):
+                    r = t[f:f + n].view(torch.int32).reshape(n, N // 32, 32 * w)
+                    assert bool((r == r[:, :1]).all().item()), f"run {rep}, frames {c * P + f}..{c * P + f + n - 1}: replicas diverged ({name})"
+                    got[name].append(t[f:f + n, :32].cpu().numpy())
+                f += n
+        for name in got:
+            assert_bits_equal(np.concatenate(got[name]), want[name], f"run {rep}: {name} of the first block, {T} frames")
+        for s_ in (9, 31, (N // 2 // 32) * 32 + 12, N - 32 + 20):
+            assert_bits_equal(b.export_state(s_), want["state"][s_ % 32], f"run {rep}: state of stream {s_} after {T} frames")
+    b.close()
+    m.close()
+
+
+def test_soak_65536_streams(blob_default):
+    """BASELINE configs[2]'s batch for 5 x 312 frames (10^8 stream-frames) on the default three-stream schedule"""
+    _soak(blob_default, 65536, reps=5, cycles=13)
+
+
+def test_soak_sparser_model_32768(blob_little):
+    """the sparser blob at 32,768 streams (the configuration in which round 4 saw replicas diverge), 5 x 312 frames"""
+    _soak(blob_little, 32768, reps=5, cycles=13)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 3])
 def test_register_fft_bit_exact(variant):
     """F1 in isolation: the register-resident 960-point transform of the analysis / synthesis kernels (fft_reg.h; reference
