@@ -39,6 +39,14 @@ RNNOISE_EXPORT int rnnoise_amd_device_count(void);
 RNNOISE_EXPORT int rnnoise_amd_set_rcp_profile(const char *name);
 RNNOISE_EXPORT const char *rnnoise_amd_rcp_profile(void);
 
+/* The reference's one libm call on the path is log10 of the band energies in double, rounded to float (src/denoise.c:383): which
+ * double comes out is a property of the HOST's libm.  The kernels restate GNU libc's algorithm (>= 2.28, the FMA build every AVX2
+ * host selects) operation for operation (rnnoise_amd/csrc/log10_glibc.h) -- bit-identical to that libm for every float band energy
+ * (swept exhaustively) -- after checking at first use that this process's libm is that one.  $RNNOISE_AMD_LOG10 = host (default) |
+ * glibc-fma | ocml (the device library's log10).  Names the model in use: "host=glibc-fma", "glibc-fma", "ocml", or
+ * "host=unknown:ocml" (a different libm: said on stderr once). */
+RNNOISE_EXPORT const char *rnnoise_amd_log10_model(void);
+
 /* Create N zero-initialised streams on `device`, all using `model` (must outlive the
  * batch, like rnnoise_create()).  NULL on error (no GPU, bad model, out of memory).
  * model==NULL fails here (the drop-in entry points rnnoise_create / rnnoise_init fall back

@@ -22,9 +22,12 @@ RNNOISE_EXPORT int rnnoise_batch_debug_pitch(RNNoiseBatch *b, float *dst);
 RNNOISE_EXPORT int rnnoise_amd_debug_fft(int device, int variant, float *out, const float *in, int n, int reps,
                                          unsigned long long *clocks, int *xlane);
 
-/* Test tap: out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on `device` (src/denoise.c:383 is the one libm call
- * of the path whose device implementation differs from the host's). Host buffers. 0 / -1. */
+/* Test tap: out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on `device` by the feature stage's own function (src/denoise.c:383
+ * is the one libm call of the path: the kernels restate the host libm's algorithm, rnnoise_amd/csrc/log10_glibc.h). Host buffers. 0 / -1.
+ * _range: ex == NULL sweeps the n floats whose bit patterns are first_bits, first_bits + 1, ... (exhaustive sweeps);
+ * model 0 = what this process's kernels use (rnnoise_amd_log10_model()), 1 = the device library's log10. */
 RNNOISE_EXPORT int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n);
+RNNOISE_EXPORT int rnnoise_amd_debug_log_energy_range(int device, float *out, const float *ex, unsigned first_bits, unsigned n, int model);
 
 /* Race hunt (tools/gru_race.py): the log of the GRU layer kernel's checking instantiations ($RNNOISE_AMD_GRU_VARIANT=w4chk ...),
  * 484 words: [0] h_old vectors that differed from HBM, [1] of them stale (= the previous unit tile's), [2] vectors checked,

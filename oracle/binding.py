@@ -115,6 +115,8 @@ class Oracle(_FrameRunner):
             L.rno_set_rcp_profile.argtypes = [C.c_char_p]
             L.rno_quantize_u8.argtypes = [C.POINTER(C.c_ubyte), C.POINTER(C.c_float), C.c_int]
             L.rno_log_energy.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+            L.rno_log_energy_range_diff.restype = C.c_uint
+            L.rno_log_energy_range_diff.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
             cls._lib = L
         return cls._lib
 
@@ -158,6 +160,15 @@ class Oracle(_FrameRunner):
         out = np.empty_like(ex)
         cls.lib().rno_log_energy(_fp(out), _fp(ex), ex.size)
         return out
+
+    @classmethod
+    def log_energy_range_diff(cls, first_bits: int, got: np.ndarray):
+        """how many of got[i] differ from (float)log10(1e-2 + (double)float_with_bits(first_bits + i)) under the host libm, and
+        the first such bit pattern (or None)"""
+        got = np.ascontiguousarray(got, np.float32)
+        first = C.c_uint(0)
+        n = cls.lib().rno_log_energy_range_diff(first_bits, got.size, _fp(got), C.byref(first))
+        return int(n), (int(first.value) if n else None)
 
     @classmethod
     def fft(cls, x_ri: np.ndarray) -> np.ndarray:

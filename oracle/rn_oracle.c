@@ -865,10 +865,25 @@ static void pitch_filter(cpx *X, const cpx *P, const float *Ex, const float *Ep,
   }
 }
 
-/* the one libm call of the feature path whose GPU counterpart is a different implementation (ocml vs glibc):
- * (float)log10(1e-2 + (double)Ex), src/denoise.c:383 -- exposed so that a test can sweep it against the device */
+/* the one libm call of the feature path: (float)log10(1e-2 + (double)Ex), src/denoise.c:383, with the HOST's libm as the
+ * reference has it -- exposed so that a test can sweep the device's restatement of that libm against it */
 void rno_log_energy(float *out, const float *Ex, int n) {
   for (int i = 0; i < n; i++) out[i] = (float)log10(1e-2 + Ex[i]);
+}
+/* the same for the n floats whose bit patterns are first_bits, first_bits + 1, ..., compared with got[]: returns how many
+ * differ bit for bit (first_bad: the first such pattern).  Exhaustive sweeps: no input array, no output array. */
+unsigned rno_log_energy_range_diff(unsigned first_bits, unsigned n, const float *got, unsigned *first_bad) {
+  unsigned bad = 0;
+  for (unsigned i = 0; i < n; i++) {
+    const unsigned u = first_bits + i;
+    float ex, want;
+    memcpy(&ex, &u, 4);
+    want = (float)log10(1e-2 + ex);
+    if (memcmp(&want, &got[i], 4)) {
+      if (!bad++ && first_bad) *first_bad = u;
+    }
+  }
+  return bad;
 }
 
 void rno_state_init(float *st) { memset(st, 0, RN_STATE_FLOATS * sizeof(float)); }
@@ -885,6 +900,15 @@ static void frame_analysis(float *analysis_mem, cpx *X, float *Ex, const float *
   forward_transform(X, xw);
   for (i = lowpass; i < NFREQ; i++) X[i].r = X[i].i = 0;
   compute_band_energy(Ex, X);
+}
+
+/* Experiment hook (tools/log10_flip_effect.py; never set by a test of the product): the `rno_flip_countdown`-th next call of
+   frame_features moves Ly[rno_flip_band] to the adjacent float before the follower uses it -- what a log10 that rounds a
+   double-rounding tie the other way would do; band -2: every band of every frame from then on -- so that its effect on the gains downstream can be measured. */
+int rno_flip_countdown = 0, rno_flip_band = -1;
+void rno_flip_log_energy(int countdown, int band) {
+  rno_flip_countdown = countdown;
+  rno_flip_band = band;
 }
 
 /* rnn_compute_frame_features (src/denoise.c:347-398) on the flat state; `training` selects the
@@ -915,9 +939,16 @@ static int frame_features(float *st, cpx *X, cpx *P, float *Ex, float *Ep, float
   features[2 * NB] = (float)(.01 * (pitch_index - 300));
   logMax = -2;
   follow = -2;
+  if (rno_flip_countdown > 0) rno_flip_countdown--;
   for (i = 0; i < NB; i++) {
     double t;
     Ly[i] = (float)log10(1e-2 + Ex[i]);
+    if (rno_flip_band == i && rno_flip_countdown == 0) {
+      Ly[i] = nextafterf(Ly[i], 1e30f);
+      rno_flip_band = -1;
+    } else if (rno_flip_band == -2 && rno_flip_countdown == 0) {  /* every band of every frame from here on */
+      Ly[i] = nextafterf(Ly[i], 1e30f);
+    }
     t = (follow - 1.5 > Ly[i]) ? follow - 1.5 : Ly[i];
     Ly[i] = (float)((logMax - 7 > t) ? logMax - 7 : t);
     logMax = (logMax > Ly[i]) ? logMax : Ly[i];

@@ -58,6 +58,7 @@ float rno_tanh(float x);
 float rno_sigmoid(float x);
 void rno_quantize_u8(unsigned char *q, const float *x, int n);
 void rno_log_energy(float *out, const float *Ex, int n); /* (float)log10(1e-2 + Ex), src/denoise.c:383 */
+unsigned rno_log_energy_range_diff(unsigned first_bits, unsigned n, const float *got, unsigned *first_bad);
 
 #ifdef __cplusplus
 }

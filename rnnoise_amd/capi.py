@@ -38,7 +38,7 @@ EXPORTS = [
     "rnnoise_model_weight_bytes", "rnnoise_batch_debug_last", "rnnoise_batch_enable_timing",
     "rnnoise_batch_kernel_ms",
     "rnnoise_batch_train_features", "rnnoise_batch_train_features_device", "rnnoise_amd_model_pack", "rnnoise_batch_set_schedule",
-    "rnnoise_amd_set_rcp_profile", "rnnoise_amd_rcp_profile",
+    "rnnoise_amd_set_rcp_profile", "rnnoise_amd_rcp_profile", "rnnoise_amd_log10_model",
 ]
 
 
@@ -57,7 +57,8 @@ def _share_hip_runtime_with_torch():
 
 
 # entry points of include/rnnoise_amd_debug.h: present in the instrumented library only
-DEBUG_EXPORTS = ["rnnoise_batch_debug_pitch", "rnnoise_amd_debug_fft", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_gru_race"]
+DEBUG_EXPORTS = ["rnnoise_batch_debug_pitch", "rnnoise_amd_debug_fft", "rnnoise_amd_debug_log_energy", "rnnoise_amd_debug_log_energy_range",
+                 "rnnoise_amd_debug_gru_race"]
 
 
 def lib():
@@ -137,12 +138,14 @@ def _load(path, debug):
         if debug:
             L.rnnoise_batch_debug_pitch.argtypes = [vp, fp]
             L.rnnoise_amd_debug_log_energy.argtypes = [C.c_int, fp, fp, C.c_int]
+            L.rnnoise_amd_debug_log_energy_range.argtypes = [C.c_int, fp, fp, C.c_uint, C.c_uint, C.c_int]
             L.rnnoise_amd_debug_gru_race.argtypes = [C.c_int, C.POINTER(C.c_uint), C.c_int]
             L.rnnoise_amd_debug_fft.argtypes = [C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), ip]
         L.rnnoise_batch_enable_timing.argtypes = [vp, C.c_int]
         L.rnnoise_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
         L.rnnoise_amd_set_rcp_profile.argtypes = [C.c_char_p]
         L.rnnoise_amd_rcp_profile.restype = C.c_char_p
+        L.rnnoise_amd_log10_model.restype = C.c_char_p
     return L
 
 
@@ -154,6 +157,12 @@ def set_rcp_profile(name: str) -> None:
 
 def rcp_profile() -> str:
     return lib().rnnoise_amd_rcp_profile().decode()
+
+
+def log10_model() -> str:
+    """which log10 the feature stage evaluates: "host=glibc-fma" (the host libm's algorithm restated on the device) | "glibc-fma" |
+    "ocml" | "host=unknown:ocml" (include/rnnoise_amd.h; $RNNOISE_AMD_LOG10)"""
+    return lib().rnnoise_amd_log10_model().decode()
 
 
 def _fp(a):

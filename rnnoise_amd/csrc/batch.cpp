@@ -551,19 +551,27 @@ extern "C" int rnnoise_amd_debug_fft(int device, int variant, float *out, const 
   return rc;
 }
 
-// out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on the device (host buffers; tests only)
-extern "C" int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n) {
-  if (!out || !ex || n <= 0) return -1;
+// out[i] = (float)log10(1e-2 + (double)ex[i]) evaluated on the device by the feature stage's function (host buffers; tests only).
+// ex == null: the n floats with bit patterns first_bits, first_bits + 1, ...; model 0: as the kernels of this process evaluate it
+// (rnnoise_amd_log10_model()), 1: the device library's log10 whatever the process uses
+extern "C" int rnnoise_amd_debug_log_energy_range(int device, float *out, const float *ex, unsigned first_bits, unsigned n, int model) {
+  if (!out || n == 0) return -1;
   ON_DEVICE(device);
+  RnTablesDev tb;
+  if (tables_for_device(device, tb)) return -1;
   float *d = nullptr;
-  HIP_OK(hipMalloc((void **)&d, (size_t)n * 8));
+  HIP_OK(hipMalloc((void **)&d, (size_t)n * (ex ? 8 : 4)));
   int rc = -1;
-  if (hipMemcpy(d, ex, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
-      rn_launch_log_energy(d, d + n, n, nullptr) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
-      hipMemcpy(out, d + n, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess)
+  if ((!ex || hipMemcpy(d + n, ex, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+      rn_launch_log_energy(ex ? d + n : nullptr, first_bits, d, n, model == 1 ? nullptr : tb.log_tab, nullptr) == hipSuccess &&
+      hipStreamSynchronize(nullptr) == hipSuccess && hipMemcpy(out, d, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess)
     rc = 0;
   hipFree(d);
   return rc;
+}
+extern "C" int rnnoise_amd_debug_log_energy(int device, float *out, const float *ex, int n) {
+  if (!ex || n <= 0) return -1;
+  return rnnoise_amd_debug_log_energy_range(device, out, ex, 0, (unsigned)n, 0);
 }
 
 // the GRU layer kernel's row-buffer check (nn_layers.hip: CHK instantiations): copies the log out and clears it

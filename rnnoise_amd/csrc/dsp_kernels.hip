@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include "rn_dev.h"
 #include "fft_reg.h"
+#include "log10_glibc.h"
 
 #define WAVE 64
 #define RN_K1_MULTI_MIN_STREAMS 6144  // from here on K1_SPW streams share a workgroup (see rn_analysis_single_kernel)
@@ -1178,7 +1179,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       float dcol[RN_NB_BANDS];
 #pragma unroll
       for (int j = 0; j < RN_NB_BANDS; j++) dcol[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
-      if (lane < RN_NB_BANDS) Ly[lane] = (float)log10(1e-2 + (double)ex0[lane]);
+      if (lane < RN_NB_BANDS) Ly[lane] = rn_log_energy(ex0[lane], tb.log_tab);
       RN_WSYNC();
       float e_sum = 0;
       {
@@ -1481,7 +1482,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float f_hi = 0;
   if (lane < RN_NB_BANDS) {
     f_hi = dct_lane(Exp, dctc, tb);
-    if (!solo) Ly[lane] = (float)log10(1e-2 + (double)Ex[lane]);
+    if (!solo) Ly[lane] = rn_log_energy(Ex[lane], tb.log_tab);
   }
   RN_WSYNC();
   // log-energy follower + total energy: 32 serial steps, evaluated uniformly.  The reference forms

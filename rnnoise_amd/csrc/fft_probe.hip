@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "fft_reg.h"
 #include "rn_dev.h"
+#include "log10_glibc.h"
 
 #define WAVE 64
 struct cpx { float r, i; };
@@ -159,14 +160,16 @@ extern "C" hipError_t rn_launch_fft_probe_lds(const float *in, float *out, unsig
   return hipGetLastError();
 }
 
-// test tap: the log-energy expression of the feature stage (src/denoise.c:383) on arbitrary inputs, so that a sweep can
-// measure how often ocml's log10 and the host libm's round a float differently (DESIGN.md section 2 "known residuals")
-extern "C" __global__ void rn_log_energy_kernel(const float *__restrict__ ex, float *__restrict__ out, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    out[i] = (float)log10(1e-2 + (double)ex[i]);
+// test tap: the log-energy expression of the feature stage (src/denoise.c:383) on arbitrary inputs -- ex[i], or, with ex == null,
+// the float whose bit pattern is first_bits + i (exhaustive sweeps without an input array) -- through the feature stage's own
+// function: tab = RnTablesDev::log_tab (the host libm's algorithm, log10_glibc.h) or null (the device library's log10)
+extern "C" __global__ void rn_log_energy_kernel(const float *__restrict__ ex, unsigned first_bits, float *__restrict__ out, unsigned n,
+                                                const double *tab) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = rn_log_energy(ex ? ex[i] : __uint_as_float(first_bits + i), tab);
 }
-extern "C" hipError_t rn_launch_log_energy(const float *ex, float *out, int n, hipStream_t st) {
-  hipLaunchKernelGGL(rn_log_energy_kernel, dim3(1024), dim3(256), 0, st, ex, out, n);
+extern "C" hipError_t rn_launch_log_energy(const float *ex, unsigned first_bits, float *out, unsigned n, const double *tab, hipStream_t st) {
+  hipLaunchKernelGGL(rn_log_energy_kernel, dim3(4096), dim3(256), 0, st, ex, first_bits, out, n, tab);
   return hipGetLastError();
 }
 

@@ -20,7 +20,7 @@
 #endif
 #include "../../include/rn_layout.h"
 
-// floats of one band-product array in LDS (the layout of RnTablesDev::band_q, shim.cpp: tables_for_device); the analysis
+// floats of one band-product array in LDS (the layout of RnTablesDev::band_q, tables.cpp: tables_for_device); the analysis
 // kernel forms two band vectors at once from two arrays this far apart
 #define RN_BAND_QSTRIDE 1044
 #define RN_SPEC_STRIDE 964  // 481 complex = 962 floats, padded to a 16-byte multiple
@@ -49,6 +49,9 @@ struct RnTablesDev {
   const uint32_t *band_chain; // [34]   per band accumulator: first slot (16-byte aligned) | number of terms << 16
   const uint16_t *band_pad;   // [64]   the floats behind an accumulator's last term up to the end of its last 16-byte slot
                               //        (48 of them; the table repeats the last): they hold +0.0f while the sums are formed
+  const double *log_tab;      // [128][2] {1/c, log c}: the table of the host libm's log() (log10_glibc.h) -- the feature stage then evaluates
+                              //         log10 operation for operation as the reference's host does; null: the device library's log10
+                              //         ($RNNOISE_AMD_LOG10=ocml, or a host whose libm is not the modelled one; tables.cpp)
   double dct_scale;           // sqrt(2./22), src/denoise.c:168
 };
 

@@ -47,7 +47,7 @@ extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
 #if RN_INSTRUMENT
-extern "C" hipError_t rn_launch_log_energy(const float *, float *, int, hipStream_t);
+extern "C" hipError_t rn_launch_log_energy(const float *, unsigned, float *, unsigned, const double *, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);
 #endif
