@@ -141,6 +141,40 @@ __device__ __forceinline__ v2f tanh_fin2(const ActPre2 &a) {
   const v2f r = a.numx * act_rcp2(a);
   return v2f{__builtin_amdgcn_fmed3f(r.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(r.y, -1.f, 1.f)};
 }
+// The same pair activations for kernels whose rcpps table sits at LDS address 0 (gru_body3 checks it): the table index IS the LDS
+// address ((bits >> 10) & 0x1ffe: no base to add -- with a dynamic-LDS base the compiler emits `v_add_u32 v, 0, v` per lookup, the
+// symbol being resolved after instruction selection), and the reconstruction is ((v << 11) + K) - exponent: v_lshl_add_u32 + v_sub
+// instead of shift, subtract, add.  2 of ~22 VALU operations per activation; the same integers, so the same bits.
+typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
+__device__ __forceinline__ ActPre2 act_pre2_lut0(v2f x, float N0, float N1, float N2, float D0, float D1, float D2) {
+  const v2f x2 = x * x;
+  const v2f num = pk_fma(pk_fma(v2f{N2, N2}, x2, v2f{N1, N1}), x2, v2f{N0, N0});
+  const v2f den = pk_fma(pk_fma(v2f{D2, D2}, x2, v2f{D1, D1}), x2, v2f{D0, D0});
+  ActPre2 a;
+  a.numx = num * x;
+  a.b0 = __float_as_uint(den.x);
+  a.b1 = __float_as_uint(den.y);
+  a.v0 = *(lds_u16_ptr)(size_t)((a.b0 >> 10) & 0x1ffeu);
+  a.v1 = *(lds_u16_ptr)(size_t)((a.b1 >> 10) & 0x1ffeu);
+  return a;
+}
+__device__ __forceinline__ v2f act_rcp2_k(const ActPre2 &a) {
+  return v2f{__uint_as_float(((a.v0 << 11) + RN_RCP_K) - (a.b0 & 0x7f800000u)), __uint_as_float(((a.v1 << 11) + RN_RCP_K) - (a.b1 & 0x7f800000u))};
+}
+__device__ __forceinline__ ActPre2 sigmoid_pre2_lut0(v2f x) {
+  return act_pre2_lut0(x, 238.13200378f, 6.02452230f, 0.00950985f, 952.72399902f, 103.34200287f, 0.74287558f);
+}
+__device__ __forceinline__ v2f sigmoid_fin2_k(const ActPre2 &a) {
+  const v2f r = pk_fma(a.numx, act_rcp2_k(a), v2f{.5f, .5f});
+  return v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};
+}
+__device__ __forceinline__ ActPre2 tanh_pre2_lut0(v2f x) {
+  return act_pre2_lut0(x, 952.52801514f, 96.39235687f, 0.60863042f, 952.72399902f, 413.36801147f, 11.88600922f);
+}
+__device__ __forceinline__ v2f tanh_fin2_k(const ActPre2 &a) {
+  const v2f r = a.numx * act_rcp2_k(a);
+  return v2f{__builtin_amdgcn_fmed3f(r.x, -1.f, 1.f), __builtin_amdgcn_fmed3f(r.y, -1.f, 1.f)};
+}
 __device__ __forceinline__ int pack4_g(float a, float b, float c, float d) {  // src/vec_avx.h:326-341, then -128 per byte
   unsigned p = 0;
   p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a, 127.f, 127.f)), 0, p);
@@ -809,6 +843,327 @@ GRU2_KERNEL(rn_nn_gru2_pbd_kernel, GRU_PERSIST | GRU_BD)
 GRU2_KERNEL(rn_nn_gru2_pall_kernel, GRU_PERSIST | GRU_BD | GRU_DEEP | GRU_AX)
 GRU2_KERNEL(rn_nn_gru2_pbdx_kernel, GRU_PERSIST | GRU_BD | GRU_AX)
 
+
+// ---- round 5, second step: THREE waves per SIMD --------------------------------------------------------------------------------
+// What the timelines (tools/gru_timeline.py, profiles/r5_gru_timeline_o0_p.txt) say about the kernels above: a 64-stream group costs
+// a CU ~66 k cycles -- 16 k of prologue in which it does nothing else, then three unit tiles per wave of 13-16 k each, of which the
+// activation stretch (~800 VALU instructions) takes 7-9 k: ONE instruction per 9-11 cycles.  A wave alone on its SIMD's VALU issues
+// at most one instruction per ~5 cycles, and its only partner is in its MFMA block (whose issue comes first).  The VALU pipe could
+// take an instruction every 2.2-4.1 cycles from two waves; with 230 VGPRs per wave there is no third wave to offer them.
+// Here the register block of a unit tile is split by GATES: first the update and reset gates (2 gates x 4 tiles: 32 accumulators,
+// 32 converted input sums), then the candidate gate (16 + 16) with z, r and h_old (48) live -- ~135 registers at the peak instead
+// of ~215, so a workgroup is TWELVE waves, two unit tiles each, three per SIMD: while one is in an MFMA block two can share the
+// VALU.  Price: the B fragments (LDS) of a unit tile are read twice, 96 KB instead of 48 -- the LDS port has the room (it was 18 %
+// busy); the A fragments (L2 -> L1 at 64 B per clock and CU, the scarcer path) still feed four MFMAs each.
+// Persistent like GRU_PERSIST above (8 + 96 + 48 KB of LDS: lut, two image pairs, one row buffer per wave).
+// Bits of OPT: GRU_BD, GRU_PERSIST, GRU3_MPRIO (a wave raises its issue priority for its MFMA blocks: the matrix pipe then never
+// waits behind a partner's VALU stream).
+#define GRU3_MPRIO 16
+#define GRU3_NOMFMA 32  // timing experiments (wrong results): the MFMA instructions / the activation arithmetic left out
+#define GRU3_NOACT 64
+#define GRU3_HITA 128   // ... every A-fragment fetch an L1 hit (the same fragment again)
+#define G3W 12
+template <int NIMG>
+struct GruLds3T {
+  uint16_t lut[4096];
+  int8_t xq[NIMG][GM][KT * 64 * 16];
+  int8_t hq[NIMG][GM][KT * 64 * 16];
+  float hrow[G3W][GM * TS][16];
+};
+static_assert(sizeof(GruLds3T<2>) <= 160 * 1024, "persistent 12-wave workgroup: one per CU");
+
+template <int AD, int NG>
+struct AFragsG {
+  v4i f[AD + 1][NG];
+};
+// A fragments of gates G0 .. G0 + NG - 1 of unit-tile row u (a0 = its lane's byte offset), k-step `step` of the rolling sequence
+template <int AD, int NG, int G0, bool HITA = false>
+__device__ __forceinline__ void a_fetch_g(AFragsG<AD, NG> &A, int step, const int8_t *__restrict__ wi, const int8_t *__restrict__ wr, unsigned a0) {
+  const int8_t *a = step < KT ? wi : wr;
+  const int kt = HITA ? 0 : (step < KT ? step : step - KT);  // (HITA, timing experiment: every fetch re-reads k-step 0's fragment -- an L1 hit)
+#pragma unroll
+  for (int gi_ = 0; gi_ < NG; gi_++) A.f[step % (AD + 1)][gi_] = ldg<v4i>(HITA ? wi : a, a0 + (unsigned)(((G0 + gi_) * 24 * KT + kt) * 1024));
+}
+template <int AD, int NG, int G0, bool BD, bool NOMFMA = false, bool HITA = false>
+__device__ __forceinline__ void int8_gates_g(v4i (&acc)[NG][GM], AFragsG<AD, NG> &A, v4i (&bf)[2][GM], int s0, const int8_t *__restrict__ wi,
+                                             const int8_t *__restrict__ wr, unsigned a0, int lane, const int8_t (*bq)[KT * 64 * 16],
+                                             const int8_t (*bq_next)[KT * 64 * 16]) {
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int kt = 0; kt < KT; kt++) {
+    const int step = s0 + kt;
+    if (step + AD < 2 * KT) a_fetch_g<AD, NG, G0, HITA>(A, step + AD, wi, wr, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!BD) b_fetch<false>(bf, 0, bq, kt, lane);
+    else if (kt + 1 < KT) b_fetch<true>(bf, (kt + 1) & 1, bq, kt + 1, lane);
+    else if (bq_next) b_fetch<true>(bf, 0, bq_next, 0, lane);
+#pragma unroll
+    for (int gi_ = 0; gi_ < NG; gi_++)
+#pragma unroll
+      for (int t = 0; t < GM; t++) {
+        if (!NOMFMA) acc[gi_][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A.f[step % (AD + 1)][gi_], bf[BD ? (kt & 1) : 0][t], acc[gi_][t], 0, 0, 0);
+        else asm volatile("" : "+v"(acc[gi_][t]) : "v"(A.f[step % (AD + 1)][gi_]), "v"(bf[BD ? (kt & 1) : 0][t]));  // (timing experiment: operands fetched, no MFMA)
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int OPT>
+__device__ __forceinline__ void gru_body3(const RnGroupDev &g, const RnModelDev &m, const RnTablesDev &tb, int layer_arg) {
+  constexpr bool BD = OPT & GRU_BD, PERSIST = OPT & GRU_PERSIST, MPRIO = OPT & GRU3_MPRIO, NOMFMA = OPT & GRU3_NOMFMA, NOACT = OPT & GRU3_NOACT, HITA = OPT & GRU3_HITA;
+  constexpr int W = G3W, AD = 2, UT = 24 / W;
+  typedef GruLds3T<PERSIST ? 2 : 1> GruLds;
+  const int layer = layer_arg & 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  GruLds &L = *reinterpret_cast<GruLds *>(lds_raw);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, gq = lane >> 4;
+  const int N = g.n_streams, n_tiles = (N + TS - 1) / TS, n_groups = (n_tiles + GM - 1) / GM;
+  if (lds_addr(L.lut) != 0) __builtin_trap();  // (the *_lut0 activations take the table index for its LDS address)
+  float *st = g.gru_state + (size_t)layer * g.n_stride * RN_GRU;
+  const int8_t *xin = g.act_q[layer];
+  int8_t *himg = g.act_q[layer + 1];
+  const RnLinearDev &wi = m.gru_in[layer], &wr = m.gru_rec[layer];
+#if RN_INSTRUMENT
+  // (timeline taps as in gru_body2: row 1 + wave of the workgroup's debug block; words 10 ui + {0 start, 1 z/r input block, 2 its conversion,
+  //  3 z/r recurrent block, 4 rows + conversion + sigmoids, 5 candidate input block, 6 candidate recurrent block, 7 tanh + blend + stores};
+  //  38 = entry, 39 = behind the prologue's barrier; the workgroup's second group: + 40)
+  unsigned *tl = (g.debug && (layer_arg & 64) && layer == 0 && lane == 0 && (blockIdx.x * GM * TS + 1 + wave) < N)
+                     ? reinterpret_cast<unsigned *>(g.debug + (size_t)(blockIdx.x * GM * TS + 1 + wave) * RN_DBG_FLOATS) : nullptr;
+  if (tl) tl[38] = (unsigned)__builtin_amdgcn_s_memtime();
+#define GRU_TL(i) do { if (tl && it < 2) tl[40 * it + 10 * ui + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GRU_TL(i) do { } while (0)
+#endif
+  auto opaque_lane = [&] {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  auto images_fetch = [&](int grp, int ib) {  // 48 pieces of 1 KB over 12 waves
+    const int l = opaque_lane();
+#pragma unroll
+    for (int j = 0; j < 2 * GM * KT / W; j++) {
+      const int c = wave + j * W, which = c / (GM * KT), cc = c - which * (GM * KT), t = cc / KT, kt = cc - t * KT;
+      const int tile = (grp * GM + t < n_tiles) ? grp * GM + t : n_tiles - 1;
+      dma_1k((which ? himg : xin) + ((size_t)tile * (KT * 64 * 16) + kt * 1024 + l * 16),
+             lds_addr(which ? L.hq[ib][t] : L.xq[ib][t]) + kt * 1024);
+    }
+  };
+  auto rows_fetch = [&](int grp, int ui) {
+    const int u = wave + W * ui, l = opaque_lane();
+#pragma unroll
+    for (int i = 0; i < GM * TS * 16 * 4 / 1024; i++) {
+      const int idx = i * 64 + l, row = idx >> 2, seg = idx & 3, s = grp * GM * TS + row, sc = s < N ? s : N - 1;
+      dma_1k(st + ((size_t)sc * RN_GRU + 16 * u + 4 * seg), lds_addr(&L.hrow[wave][0][0]) + i * 1024);
+    }
+  };
+
+  int grp = blockIdx.x;
+  images_fetch(grp, 0);
+  if (wave < 8) dma_1k(reinterpret_cast<const uint32_t *>(tb.rcp16) + wave * 256 + lane * 4, lds_addr(L.lut) + wave * 1024);
+  rows_fetch(grp, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#if RN_INSTRUMENT
+  if (tl) tl[39] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+
+#pragma unroll 1
+  for (int it = 0;; it++) {
+    const int ib = PERSIST ? (it & 1) : 0, tile0 = grp * GM;
+    const int next_grp = grp + (int)gridDim.x;
+    const bool has_next = PERSIST && next_grp < n_groups;
+    unsigned livemask = 0;
+#pragma unroll
+    for (int t = 0; t < GM; t++) {
+      const int s = (tile0 + t) * TS + n, sc = s < N ? s : N - 1;
+      livemask |= (s < N && !g.silence[(unsigned)sc]) ? 1u << t : 0u;  // silent streams keep their state (src/denoise.c:474)
+    }
+#pragma unroll 1
+    for (int ui = 0; ui < UT; ui++) {
+      const int u = wave + W * ui, unit0 = 16 * u + 4 * gq;
+      const unsigned a0 = (unsigned)(u * KT * 64 + lane) * 16u;
+      auto row4 = [&](int gate) { return (unsigned)(gate * RN_GRU + unit0) * 4u; };  // byte offset of the lane's 4 rows of a gate
+      GRU_TL(0);
+      v4i bf[2][GM];
+      v4f h_old[GM], z[GM], rg[GM];
+      {  // ---- update and reset gates ----
+        v4i acc[2][GM];
+        v4f gi[2][GM];
+        AFragsG<AD, 2> A;
+#pragma unroll
+        for (int gate = 0; gate < 2; gate++) {
+          const v4i rs = ldg<v4i>(wi.rowsum128, row4(gate));  // (acc_x86 = acc_mfma + 128 rowsum(w))
+#pragma unroll
+          for (int t = 0; t < GM; t++) acc[gate][t] = rs;
+        }
+#pragma unroll
+        for (int step = 0; step < AD; step++) a_fetch_g<AD, 2, 0, HITA>(A, step, wi.wmf, wr.wmf, a0);
+        if (BD) b_fetch<true>(bf, 0, L.xq[ib], 0, lane);
+        if (MPRIO) __builtin_amdgcn_s_setprio(2);
+        int8_gates_g<AD, 2, 0, BD, NOMFMA, HITA>(acc, A, bf, 0, wi.wmf, wr.wmf, a0, lane, L.xq[ib], L.hq[ib]);
+        GRU_TL(1);
+#pragma unroll
+        for (int gate = 0; gate < 2; gate++) {  // float(acc_x86)*scale + subias (src/nnet_arch.h:145-151)
+          const v4f sc = ldg<v4f>(wi.scale, row4(gate));
+          const v4f sb = ldg<v4f>(wi.bias, row4(gate));
+          const v4i rs = ldg<v4i>(wr.rowsum128, row4(gate));
+#pragma unroll
+          for (int t = 0; t < GM; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) gi[gate][t][r] = (float)acc[gate][t][r] * sc[r] + sb[r];
+            acc[gate][t] = rs;
+          }
+        }
+        GRU_TL(2);
+        int8_gates_g<AD, 2, 0, BD, NOMFMA, HITA>(acc, A, bf, KT, wi.wmf, wr.wmf, a0, lane, L.hq[ib], nullptr);
+        if (MPRIO) __builtin_amdgcn_s_setprio(0);
+        GRU_TL(3);
+        // all of this wave's loads have landed (the last A fragment was just used): its f32 rows for this unit tile are in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < GM; t++) h_old[t] = *reinterpret_cast<const v4f *>(&L.hrow[wave][TS * t + n][4 * gq]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the row buffer is free: the next unit tile's rows (and, once per group, the next group's images) start their trip under the
+        // sigmoids below, which load nothing but six constant vectors
+        __builtin_amdgcn_sched_barrier(0);
+        if (ui + 1 < UT) rows_fetch(grp, ui + 1);
+        else if (has_next) rows_fetch(next_grp, 0);
+        if (PERSIST && ui == 0 && has_next) images_fetch(next_grp, ib ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // gate by gate (the update gate's accumulators and input sums are dead before the reset gate's conversion starts: the
+        // register peak of the unit tile), the eight pair lookups of a gate's four tiles in flight together
+#pragma unroll
+        for (int gate = 0; gate < 2; gate++) {
+          const v4f sc = ldg<v4f>(wr.scale, row4(gate));
+          const v4f sb = ldg<v4f>(wr.bias, row4(gate));
+          const v4f dg = ldg<v4f>(wr.diag, row4(gate));
+          // (two tiles = four pair lookups in flight at a time: with all four tiles' the compiler ran out of its 168 registers and
+          //  spilled the looked-up entries one by one)
+#pragma unroll
+          for (int th = 0; th < GM; th += 2) {
+            ActPre2 ap[2][2];
+#pragma unroll
+            for (int t = th; t < th + 2; t++) {
+              v4f gr;
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                gr[r] = (float)acc[gate][t][r] * sc[r] + sb[r];
+                gr[r] += dg[r] * h_old[t][r];  // src/nnet_arch.h:153-161
+              }
+#pragma unroll
+              for (int p = 0; p < 2; p++) {
+                const v2f gv = {gi[gate][t][2 * p], gi[gate][t][2 * p + 1]}, rv = {gr[2 * p], gr[2 * p + 1]};
+                if (!NOACT) ap[t - th][p] = sigmoid_pre2_lut0(gv + rv);
+                else ap[t - th][p].numx = gv + rv;  // (timing experiment: no activation arithmetic, no lookups)
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = th; t < th + 2; t++)
+#pragma unroll
+              for (int p = 0; p < 2; p++) {
+                v2f o = NOACT ? ap[t - th][p].numx : sigmoid_fin2_k(ap[t - th][p]);
+                // (pinned: the compiler otherwise sinks this half of the activation to its use behind the candidate's MFMA blocks
+                //  and keeps its six inputs per pair alive instead of the two results -- 30 dwords of scratch per unit tile)
+                asm volatile("" : "+v"(o.x), "+v"(o.y));
+                if (gate == 0) {
+                  z[t][2 * p] = o.x;
+                  z[t][2 * p + 1] = o.y;
+                } else {
+                  rg[t][2 * p] = o.x;
+                  rg[t][2 * p + 1] = o.y;
+                }
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      GRU_TL(4);
+      {  // ---- candidate gate, blend, stores ----
+        v4i acc[1][GM];
+        v4f gi[GM];
+        AFragsG<AD, 1> A;
+        {
+          const v4i rs = ldg<v4i>(wi.rowsum128, row4(2));
+#pragma unroll
+          for (int t = 0; t < GM; t++) acc[0][t] = rs;
+        }
+#pragma unroll
+        for (int step = 0; step < AD; step++) a_fetch_g<AD, 1, 2, HITA>(A, step, wi.wmf, wr.wmf, a0);
+        if (BD) b_fetch<true>(bf, 0, L.xq[ib], 0, lane);
+        if (MPRIO) __builtin_amdgcn_s_setprio(2);
+        int8_gates_g<AD, 1, 2, BD, NOMFMA, HITA>(acc, A, bf, 0, wi.wmf, wr.wmf, a0, lane, L.xq[ib], L.hq[ib]);
+        GRU_TL(5);
+        {
+          const v4f sc = ldg<v4f>(wi.scale, row4(2));
+          const v4f sb = ldg<v4f>(wi.bias, row4(2));
+          const v4i rs = ldg<v4i>(wr.rowsum128, row4(2));
+#pragma unroll
+          for (int t = 0; t < GM; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) gi[t][r] = (float)acc[0][t][r] * sc[r] + sb[r];
+            acc[0][t] = rs;
+          }
+        }
+        int8_gates_g<AD, 1, 2, BD, NOMFMA, HITA>(acc, A, bf, KT, wi.wmf, wr.wmf, a0, lane, L.hq[ib], nullptr);
+        if (MPRIO) __builtin_amdgcn_s_setprio(0);
+        GRU_TL(6);
+        const v4f sc = ldg<v4f>(wr.scale, row4(2));
+        const v4f sb = ldg<v4f>(wr.bias, row4(2));
+        const v4f dg = ldg<v4f>(wr.diag, row4(2));
+#pragma unroll
+        for (int t = 0; t < GM; t++) {
+          v4f gr, hn;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            gr[r] = (float)acc[0][t][r] * sc[r] + sb[r];
+            gr[r] += dg[r] * h_old[t][r];
+          }
+          ActPre2 ah[2];
+#pragma unroll
+          for (int p = 0; p < 2; p++) {
+            const v2f gh = {gi[t][2 * p], gi[t][2 * p + 1]}, rh = {gr[2 * p], gr[2 * p + 1]}, rv = {rg[t][2 * p], rg[t][2 * p + 1]};
+            if (!NOACT) ah[p] = tanh_pre2_lut0(gh + rh * rv);
+            else ah[p].numx = gh + rh * rv;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 2; p++) {
+            const v2f ho = {h_old[t][2 * p], h_old[t][2 * p + 1]}, zz = {z[t][2 * p], z[t][2 * p + 1]};
+            const v2f hv = zz * ho + (v2f{1.f, 1.f} - zz) * (NOACT ? ah[p].numx : tanh_fin2_k(ah[p]));
+            hn[2 * p] = hv.x;
+            hn[2 * p + 1] = hv.y;
+          }
+          if (livemask >> t & 1) {  // (live implies tile0 + t < n_tiles and its stream < N)
+            stg<v4f>(st, (unsigned)(((tile0 + t) * TS + n) * RN_GRU + unit0) * 4u, hn);
+            stg<int>(himg, (unsigned)((tile0 + t) * (KT * 64 * 16) + frag_off(n, unit0)), pack4_g(hn[0], hn[1], hn[2], hn[3]));
+          }
+        }
+      }
+      GRU_TL(7);
+    }
+    if (!has_next) break;
+    grp = next_grp;
+    // (see gru_body2: every wave's image pieces were issued in its first unit tile and drained by the vmcnt(0) of its second)
+    __builtin_amdgcn_s_barrier();
+  }
+#undef GRU_TL
+}
+#define GRU3_KERNEL(name, opt)                                                                                                        \
+  extern "C" __global__ void __launch_bounds__(64 * G3W) name(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {             \
+    gru_body3<opt>(g, m, tb, layer);                                                                                                  \
+  }
+GRU3_KERNEL(rn_nn_gru3_kernel, GRU_PERSIST | GRU_BD)
+GRU3_KERNEL(rn_nn_gru3_nobd_kernel, GRU_PERSIST)
+GRU3_KERNEL(rn_nn_gru3_np_kernel, GRU_BD)
+GRU3_KERNEL(rn_nn_gru3_mprio_kernel, GRU_PERSIST | GRU_BD | GRU3_MPRIO)
+GRU3_KERNEL(rn_nn_gru3_nomfma_kernel, GRU_PERSIST | GRU_BD | GRU3_NOMFMA)
+GRU3_KERNEL(rn_nn_gru3_noact_kernel, GRU_PERSIST | GRU_BD | GRU3_NOACT)
+GRU3_KERNEL(rn_nn_gru3_neither_kernel, GRU_PERSIST | GRU_BD | GRU3_NOACT | GRU3_NOMFMA)
+GRU3_KERNEL(rn_nn_gru3_hita_kernel, GRU_PERSIST | GRU_BD | GRU3_HITA)
+GRU3_KERNEL(rn_nn_gru3_hita_neither_kernel, GRU_PERSIST | GRU_BD | GRU3_HITA | GRU3_NOACT | GRU3_NOMFMA)
+
 extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
   gru_body<2, 8, 3, false>(g, m, tb, layer);
 }
@@ -867,6 +1222,13 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
       {"bdx", rn_nn_gru2_bdx_kernel, 512, sizeof(GruLds2T<1>), false},      {"p", rn_nn_gru2_p_kernel, 512, sizeof(GruLds2T<2>), true},
       {"pbd", rn_nn_gru2_pbd_kernel, 512, sizeof(GruLds2T<2>), true},       {"pall", rn_nn_gru2_pall_kernel, 512, sizeof(GruLds2T<2>), true},
       {"pbdx", rn_nn_gru2_pbdx_kernel, 512, sizeof(GruLds2T<2>), true},
+      // ... second step (gru_body3): twelve waves, the unit tile's register block split by gates
+      {"v3", rn_nn_gru3_kernel, 768, sizeof(GruLds3T<2>), true},            {"v3nobd", rn_nn_gru3_nobd_kernel, 768, sizeof(GruLds3T<2>), true},
+      {"v3np", rn_nn_gru3_np_kernel, 768, sizeof(GruLds3T<1>), false},      {"v3mprio", rn_nn_gru3_mprio_kernel, 768, sizeof(GruLds3T<2>), true},
+      // timing experiments, wrong results (what a part costs = what leaving it out saves):
+      {"v3nomfma", rn_nn_gru3_nomfma_kernel, 768, sizeof(GruLds3T<2>), true}, {"v3noact", rn_nn_gru3_noact_kernel, 768, sizeof(GruLds3T<2>), true},
+      {"v3neither", rn_nn_gru3_neither_kernel, 768, sizeof(GruLds3T<2>), true},
+      {"v3hita", rn_nn_gru3_hita_kernel, 768, sizeof(GruLds3T<2>), true},   {"v3hitaneither", rn_nn_gru3_hita_neither_kernel, 768, sizeof(GruLds3T<2>), true},
 #if RN_INSTRUMENT
       {"w4chk", rn_nn_gru_w4_chk_kernel, 256, sizeof(GruLdsT<4, 1>), false}, {"w8b1chk", rn_nn_gru_w8b1_chk_kernel, 512, sizeof(GruLdsT<8, 1>), false},
       {"w8chk", rn_nn_gru_chk_kernel, 512, sizeof(GruLdsT<8, 3>), false},
@@ -876,7 +1238,7 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
   // $RNNOISE_AMD_GRU_VARIANT (A/B runs; an unknown name is an error, not a silent default)
   static const int vi = [] {
     const char *e = getenv("RNNOISE_AMD_GRU_VARIANT");
-    if (!e || !*e) return 0;
+    if (!e || !*e) e = "w4";  // round 5: four waves, 72 KB -- two workgroups per CU (1-3 % under "w8" stand-alone in every A/B of profiles/r5_gru_bound.txt)
     for (int i = 0; i < NV; i++)
       if (!strcmp(e, variants[i].name)) return i;
     fprintf(stderr, "[rnnoise_amd] RNNOISE_AMD_GRU_VARIANT=%s: no such variant in this build\n", e);

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DEFAULT = ["w8", "w8b1", "o0", "bd", "deep", "ax", "bdx", "p", "pbd", "pbdx", "pall", "w4"]
+DEFAULT = ["w8", "w4", "p", "v3", "v3nobd", "v3np", "v3mprio"]
 N_PAR, CALLS = 20000, (3, 1, 6)
 
 
