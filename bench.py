@@ -350,9 +350,10 @@ def pin_rank_cpus(local_rank: int, local_world: int, torch) -> None:
     try:
         cpus = sorted(os.sched_getaffinity(0))
         per = len(cpus) // local_world
+        share = usable_cpus() // local_world  # (this rank's part of the job's quota: taken BEFORE the affinity is narrowed)
         if per >= 1:
             os.sched_setaffinity(0, cpus[local_rank * per:(local_rank + 1) * per])
-        torch.set_num_threads(max(1, min(per, usable_cpus() // local_world)))
+        torch.set_num_threads(max(1, min(per, share)))
     except (AttributeError, OSError):
         pass
 
@@ -384,6 +385,44 @@ def workload_name(a, n_streams: int) -> str:
             + (f", {a.frames_per_call} frame(s) per call" if a.frames_per_call else ""))
 
 
+def open_collectives(torch, rank: int, world: int, dev, data_backend):
+    """The job's two process groups.  CONTROL = gloo, always (rendezvous, object gathers, the agreement below): it needs nothing
+    but TCP on 127.0.0.1.  DATA = RCCL over xGMI for the barriers around the timed regions and the MAX all-reduce of the times
+    (north_star: "RCCL only for the final throughput reduction") -- created and TRIED here, once, with a timeout, and every rank
+    votes over gloo on whether its try worked: one rank without a working communicator (or all of them) sends the whole job to
+    gloo for the data group as well, and the line says so ("collective": "gloo-fallback" + the first error) instead of the run
+    dying, or hanging, in its first collective.  Returns (dist, data_group, "rccl" | "gloo" | "gloo-fallback", error text or None)."""
+    import datetime
+
+    import torch.distributed as dist
+    # a failed or timed-out RCCL collective must RAISE here, not abort the process from the watchdog thread
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    if not data_backend:
+        return dist, None, "gloo", None
+    group, err = None, None
+    try:
+        if os.environ.get("RNNOISE_AMD_BENCH_BREAK_RCCL") == str(rank):  # (tests: this rank's communicator "fails")
+            raise RuntimeError("RCCL failure injected by RNNOISE_AMD_BENCH_BREAK_RCCL")
+        group = dist.new_group(backend=data_backend, timeout=datetime.timedelta(seconds=float(os.environ.get("RNNOISE_AMD_BENCH_DATA_TIMEOUT", "90"))))
+        probe = torch.ones(1, device=dev if data_backend == "nccl" else "cpu")
+        dist.all_reduce(probe, group=group)
+        if data_backend == "nccl":
+            torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks returned {probe.item()}")
+    except Exception as e:  # noqa: BLE001 -- whatever the runtime throws: the vote decides
+        err = f"rank {rank}: {type(e).__name__}: {str(e)[:300]}"
+        print(f"[bench] {err}", file=sys.stderr, flush=True)
+    votes = [None] * world
+    dist.all_gather_object(votes, err)
+    bad = [v for v in votes if v]
+    if bad:
+        return dist, None, "gloo-fallback", bad[0]
+    return dist, group, "rccl" if data_backend == "nccl" else data_backend, None
+
+
 def bench_rank(a) -> dict | None:
     """One rank of the benchmark (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Returns the JSON line's dict
     on rank 0, None elsewhere."""
@@ -405,15 +444,14 @@ def bench_rank(a) -> dict | None:
     if not stub:
         torch.cuda.set_device(gpu_index)
     pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch)
-    dist = None
+    dist, data_group, collective, collective_error = None, None, None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub or share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    red_dev = torch.device("cpu") if (stub or share) else dev  # where the reduction's tensors live
+        # (tests: RNNOISE_AMD_BENCH_DATA_BACKEND=gloo sends the stub through the same create / try / vote code with a gloo data group)
+        backend = os.environ.get("RNNOISE_AMD_BENCH_DATA_BACKEND") or (None if (stub or share) else "nccl")
+        dist, data_group, collective, collective_error = open_collectives(torch, rank, world, dev, backend)
+    red_dev = dev if collective == "rccl" else torch.device("cpu")  # where the reduction's tensors live
 
     def sync():
         if not stub:
@@ -422,7 +460,7 @@ def bench_rank(a) -> dict | None:
     def barrier():
         sync()
         if dist:
-            dist.barrier()
+            dist.barrier(group=data_group)
         sync()
 
     # weak scaling: `streams` per GPU; this rank's global stream ids seed its signals
@@ -499,11 +537,13 @@ def bench_rank(a) -> dict | None:
         kms_alone = batch.kernel_ms()
         batch.set_schedule(old)
     batch.enable_timing(False)
-    times = aggregate_times(times, dist, red_dev)  # element-wise MAX over ranks
-    shards = [[mine.start, mine.stop]]
-    if dist:
-        shards = [None] * world
+    own_median = statistics.median(times)
+    times = aggregate_times(times, dist, red_dev, group=data_group)  # element-wise MAX over ranks: the one data-path collective
+    shards, rank_medians = [[mine.start, mine.stop]], [own_median]
+    if dist:  # (object gathers ride on the gloo control group)
+        shards, rank_medians = [None] * world, [None] * world
         dist.all_gather_object(shards, [mine.start, mine.stop])
+        dist.all_gather_object(rank_medians, own_median)
     frames_per_rep = float(N * K * world)
     med = statistics.median(times)
     line = None
@@ -533,6 +573,8 @@ def bench_rank(a) -> dict | None:
             "data": "synthetic" + (", fed from and returned to pinned host memory over PCIe inside the timed region" if a.host_io else ""),
             "value_min": round(frames_per_rep / max(times), 1), "value_max": round(frames_per_rep / min(times), 1),
             "repeats": R,
+            # each rank's own rate (its frames / the median of ITS repetition times): the aggregate is paced by the slowest
+            "value_by_rank": [round(N * K / t, 1) for t in rank_medians],
             "config": {"workload": workload_name(a, N), "streams_per_gpu": N, "frames_per_step": N * world,
                        "nn_path": a.nn, "model": a.model, "outputs_sane": sane,
                        "stream_ids_rank0": [mine.start, mine.stop], "stream_ids_by_rank": shards},
@@ -617,6 +659,10 @@ def bench_rank(a) -> dict | None:
             line["stub"] = True
         if share and world > 1:
             line["shared_device"] = True
+        if world > 1:
+            line["collective"] = collective
+            if collective_error:
+                line["collective_error"] = collective_error
         if not stub and not a.no_parity:
             try:
                 line["parity"] = parity_leg(capi, torch, batch, blob, d_in_f32, min(cap, 12), a.s16)
@@ -648,8 +694,13 @@ def parse_args(argv=None):
                     help="frames per library call (0 = as many as the step count allows; 1 = the cadence of a real-time server)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--smoke", action="store_true",
+                    help="a two-step, one-repetition run of the same path (launcher, collectives, sharding, parity leg): what to run first on a new node")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # launcher self-test on CPU (gloo)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.smoke:
+        a.steps, a.warmup, a.repeats, a.no_cpu_baseline = 2, 1, 1, True
+    return a
 
 
 def main():

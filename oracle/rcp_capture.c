@@ -12,7 +12,7 @@
  *     bits(rcp(x)) = (t[(bits(x) >> 11) & 0xfff] << 11) + 0x3f000000 - ((bits(x) & 0x7f800000) - 0x3f800000)
  *
  * The product carries the tables of both families (rnnoise_amd/csrc/rcp_profiles.h) and, by default, re-captures
- * the 4096 entries from the CPU it is running on at load time (shim.cpp: rcp profile "host").
+ * the 4096 entries from the CPU it is running on at load time (tables.cpp: rcp profile "host").
  *
  * Usage: rcp_capture INTEL ../rnnoise_amd/csrc/rcp_profile_intel.h   (exit status 0 only if the model held exhaustively)
  */

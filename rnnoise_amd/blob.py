@@ -183,7 +183,7 @@ _PACK_LAYER = struct.Struct("<9Q4I4i")       # 9 offsets, 4 flags, nin, nout, nb
 
 def pack(blob: bytes) -> bytes:
     """"DNNw" blob -> GPU-native "RNPK" pack.  The layouts are produced by the library itself (the same code that stages a
-    blob for the GPU: rnnoise_amd/csrc/shim.cpp stage_linear), so a pack is bit-for-bit what a blob load would upload."""
+    blob for the GPU: rnnoise_amd/csrc/model.cpp stage_linear), so a pack is bit-for-bit what a blob load would upload."""
     from . import capi
     m = capi.Model(blob)
     try:

@@ -13,42 +13,83 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // device-resident one-stream states (rnnoise_create / rnnoise_destroy)
 // ---------------------------------------------------------------------------------------------
+int pool_rows() {
+  static const int n = [] {
+    const char *e = getenv("RNNOISE_AMD_POOL_ROWS");
+    int v = e && *e ? atoi(e) : RN_POOL_ROWS_MAX;
+    v = std::max(64, std::min(RN_POOL_ROWS_MAX, v));
+    return (v + 63) & ~63;
+  }();
+  return n;
+}
+
 StatePool *pool_new(RNNModel *model, int device) {
   StatePool *p = new StatePool();
-  p->batch = rnnoise_batch_create(model, StatePool::POOL_SLOTS, device);
+  p->rows = pool_rows();
+  p->batch = rnnoise_batch_create(model, p->rows, device);
   if (!p->batch) {
     delete p;
     return nullptr;
   }
   DeviceGuard guard(device);
   if (!guard.ok ||
-      hipHostMalloc((void **)&p->h_io, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-      hipMalloc((void **)&p->d_flat, (size_t)StatePool::POOL_SLOTS * StatePool::FLAT_BLK * sizeof(float)) != hipSuccess) {
+      hipHostMalloc((void **)&p->h_io, (size_t)p->rows * RN_ROW_IO * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+      hipMalloc((void **)&p->d_flat, (size_t)StatePool::FLAT_ROWS * StatePool::FLAT_BLK * sizeof(float)) != hipSuccess) {
     if (p->h_io) hipHostFree(p->h_io);
     rnnoise_batch_destroy(p->batch);
     delete p;
     return nullptr;
   }
-  memset(p->h_io, 0, (size_t)StatePool::POOL_SLOTS * RN_ROW_IO * sizeof(float));
+  memset(p->h_io, 0, (size_t)p->rows * RN_ROW_IO * sizeof(float));
+  p->used.assign(p->rows / 64, 0ull);
+  p->req = static_cast<int *>(calloc(p->rows, sizeof(int)));
+  p->sleeping = static_cast<int *>(calloc(p->rows, sizeof(int)));
+  // launch groups run the latency network kernel (rn_nn_one_kernel, 125 KB of LDS by opt-in): where it cannot run, pooled frames go
+  // through pool_step one state at a time, which has the vector kernel to fall back on
+  p->comb.no_nn_one = nn_one_max_streams() < 1;
   return p;
 }
 
-// a free row of one of the model's pools on device 0 (a new pool when all are full); zeroed like rnnoise_init()
-int pool_acquire(RNNModel *model, StatePool *&pool, int &slot) {
+// Which device a NEW pool goes to.  $RNNOISE_AMD_DEVICE = <index>: that one.  Otherwise the visible devices in turn (the k-th pool of
+// a model on device k mod count): the reference lets a process hold any number of independent states (include/rnnoise.h:80,
+// src/denoise.c:311-321); on a multi-GPU node a few hundred of them each should not all land on device 0.
+int pool_device_for(size_t n_pools_so_far) {
+  static const int pinned = [] {
+    const char *e = getenv("RNNOISE_AMD_DEVICE");
+    return e && *e ? atoi(e) : -1;
+  }();
+  const int count = std::max(1, rnnoise_amd_device_count());
+  if (pinned >= 0) return std::min(pinned, count - 1);
+  return (int)(n_pools_so_far % (size_t)count);
+}
+
+// a free row of one of the model's pools (a new pool when all are full); zeroed like rnnoise_init().  max_row: rows below it only
+// (self-contained states stage through d_flat, which has FLAT_ROWS blocks).
+int pool_acquire(RNNModel *model, StatePool *&pool, int &slot, int max_row = RN_POOL_ROWS_MAX) {
   std::unique_lock<std::mutex> lk(model->mu);
   for (int pass = 0; pass < 2; pass++) {
     for (StatePool *p : model->pools) {
       std::lock_guard<std::mutex> pl(p->mu);
-      if (~p->used) {
-        slot = __builtin_ctzll(~p->used);
-        p->used |= 1ull << slot;
-        pool = p;
-        return 0;
+      // rnnoise_create() states take rows from the top, borrowed rows (max_row = FLAT_ROWS) from the bottom: the two kinds do not
+      // crowd each other out of a pool
+      const bool from_top = max_row >= p->rows;
+      const int words = std::min((int)p->used.size(), (max_row + 63) / 64);
+      for (int i = 0; i < words; i++) {
+        const int w = from_top ? words - 1 - i : i;
+        if (~p->used[w]) {
+          const int bit = from_top ? 63 - __builtin_clzll(~p->used[w]) : __builtin_ctzll(~p->used[w]);
+          if (w * 64 + bit >= max_row) break;
+          p->used[w] |= 1ull << bit;
+          slot = w * 64 + bit;
+          pool = p;
+          return 0;
+        }
       }
     }
     if (pass == 0) {
+      const int device = pool_device_for(model->pools.size());
       lk.unlock();  // rnnoise_batch_create takes the model lock itself
-      StatePool *p = pool_new(model, 0);
+      StatePool *p = pool_new(model, device);
       lk.lock();
       if (!p) return -1;
       model->pools.push_back(p);
@@ -59,7 +100,7 @@ int pool_acquire(RNNModel *model, StatePool *&pool, int &slot) {
 
 void pool_release(StatePool *p, int slot) {
   std::lock_guard<std::mutex> pl(p->mu);
-  p->used &= ~(1ull << slot);
+  p->used[slot >> 6] &= ~(1ull << (slot & 63));
 }
 
 // the stateful arrays of one row back to all-zero (what rnnoise_init does to a DenoiseState, src/denoise.c:286)
@@ -163,19 +204,20 @@ int effective_cpus() {
   return n;
 }
 long futex(int *addr, int op, int val) { return syscall(SYS_futex, addr, op, val, nullptr, nullptr, 0); }
-inline volatile uint32_t *done_word(PooledRef *m) { return reinterpret_cast<volatile uint32_t *>(m->h_io + RN_ROW_IO - 1); }
+inline volatile uint32_t *done_word(StatePool *p, int slot) { return reinterpret_cast<volatile uint32_t *>(p->h_io + (size_t)slot * RN_ROW_IO + RN_ROW_IO - 1); }
 
 // Retire the entries of a group (combiner lock held): an entry's request goes INFLIGHT / SYNCER -> `state` unless its
 // caller has already seen its frame come out and left (it may be back with a new request under a new sequence number:
 // the compare-and-swap then fails and the new request is left alone).  Returns the callers asleep on their word: they are
 // woken after the lock is dropped, by address only.
-void comb_retire(const std::vector<CombMember> &grp, int state, PooledRef *self, std::vector<int *> &wake) {
+void comb_retire(StatePool *p, const std::vector<CombMember> &grp, int state, PooledRef *self, std::vector<int *> &wake) {
   for (const CombMember &e : grp) {
     if (e.ref == self) continue;
     for (int from : {REQ_INFLIGHT, REQ_SYNCER}) {
       int expect = req_word(e.seq, from);
-      if (__atomic_compare_exchange_n(&e.ref->req, &expect, req_word(e.seq, state), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
-        if (__atomic_load_n(&e.ref->sleeping, __ATOMIC_SEQ_CST)) wake.push_back(&e.ref->req);
+      if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, state), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+        // (the row's words are the pool's: reading them is safe even if the state has just taken its frame and been destroyed)
+        if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) wake.push_back(&p->req[e.slot]);
         break;
       }
     }
@@ -201,14 +243,20 @@ int comb_free_stream(StatePool *p) {  // (lock held) a stream without a group in
 }
 
 // (lock held) everything queued becomes the group in flight on stream k
-void comb_take_queue(Combiner &c, int k, std::vector<CombMember> &grp) {
-  grp.swap(c.queue);
-  c.queue.clear();
+void comb_take_queue(StatePool *p, int k, std::vector<CombMember> &grp) {
+  Combiner &c = p->comb;
+  if (c.queue.size() <= (size_t)RN_ROWS_MAX) {
+    grp.swap(c.queue);
+    c.queue.clear();
+  } else {  // (a pool has more rows than a row list has entries: the oldest RN_ROWS_MAX requests go, the rest stay queued)
+    grp.assign(c.queue.begin(), c.queue.begin() + RN_ROWS_MAX);
+    c.queue.erase(c.queue.begin(), c.queue.begin() + RN_ROWS_MAX);
+  }
   c.busy[k] = true;
   c.members[k] = grp;
   for (const CombMember &e : grp) {
     e.ref->grp = k;
-    __atomic_store_n(&e.ref->req, req_word(e.seq, REQ_INFLIGHT), __ATOMIC_SEQ_CST);  // (a queued request's caller is waiting on it)
+    __atomic_store_n(&p->req[e.slot], req_word(e.seq, REQ_INFLIGHT), __ATOMIC_SEQ_CST);  // (a queued request's caller is waiting on it)
   }
 }
 
@@ -216,11 +264,14 @@ void comb_take_queue(Combiner &c, int k, std::vector<CombMember> &grp) {
 int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   RNNoiseBatch *b = p->batch;
   RnRows rows;
-  rows.io = p->h_io;  // (pinned host memory is mapped into the device's address space at the same address)
+  // (mapped, coherent pinned memory: the device's alias of the block -- the same address under unified addressing, asked for all the same)
+  void *d_io = nullptr;
+  HIP_OK(hipHostGetDevicePointer(&d_io, p->h_io, 0));
+  rows.io = static_cast<float *>(d_io);
   rows.n = (int)grp.size();
   for (int i = 0; i < rows.n; i++) {
     const PooledRef *m = grp[i].ref;
-    rows.e[i] = (uint32_t)m->slot | ((uint32_t)m->ring_slot << 8) | ((uint32_t)m->parity << 12) | (grp[i].seq << 16);
+    rows.e[i] = RN_ROW_ENTRY(m->slot, m->ring_slot, m->parity, grp[i].seq);
   }
   for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
   hipStream_t st = p->comb.stream[k];
@@ -239,9 +290,13 @@ void comb_abort(StatePool *p, int k, const std::vector<CombMember> &grp, PooledR
   std::vector<int *> wake;
   {
     std::lock_guard<std::mutex> lk(c.mu);
+    // the high-pass of the group may have run before the failing launch: the members' pitch rings may already hold this frame,
+    // which their host-side ring slot will not count.  Every member restarts from zero at its next call (its caller is still
+    // blocked on its request word: the entry's state is alive here).
+    for (const CombMember &e : grp) __atomic_store_n(&e.ref->poisoned, 1, __ATOMIC_SEQ_CST);
     c.members[k].clear();
     c.busy[k] = false;
-    comb_retire(grp, REQ_DONE_FAIL, self, wake);
+    comb_retire(p, grp, REQ_DONE_FAIL, self, wake);
   }
   comb_wake(wake);
 }
@@ -256,6 +311,7 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
   // stream is synchronised instead (which is also where a GPU fault would surface).
   static const bool poll = env_int("RNNOISE_AMD_COMBINE_POLL", 1) != 0;
   bool self_ok = true;
+  const uint64_t t_begin = now_ns();
   for (bool first = true;; first = false) {
     std::vector<CombMember> done, next;
     {
@@ -267,10 +323,14 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
       const uint64_t give_up = now_ns() + 2000000ull;
       for (const CombMember &e : done)
         // (a member that has left and come back has cleared its word for its next request: the old frame is out)
-        for (unsigned it = 0; flagged && *done_word(e.ref) != e.seq && (__atomic_load_n(&e.ref->req, __ATOMIC_SEQ_CST) >> 4) == (int)e.seq; it++) {
+        for (unsigned it = 0; flagged && *done_word(p, e.slot) != e.seq && (__atomic_load_n(&p->req[e.slot], __ATOMIC_SEQ_CST) >> 4) == (int)e.seq; it++) {
           cpu_relax();
           if ((it & 255) == 255 && now_ns() > give_up) flagged = false;
         }
+    }
+    if (first && flagged) {  // how long a group takes from its launch to its frames: the followers' sleep is sized by it
+      const uint64_t dt = now_ns() - t_begin, old = c.group_ns.load(std::memory_order_relaxed);
+      c.group_ns.store(old ? (3 * old + dt) / 4 : dt, std::memory_order_relaxed);
     }
     bool ok = true;
     if (!flagged) {
@@ -282,9 +342,9 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
     {
       std::lock_guard<std::mutex> lk(c.mu);
       c.members[k].clear();
-      if (!c.queue.empty() && !c.gathering) comb_take_queue(c, k, next);
+      if (!c.queue.empty() && !c.gathering) comb_take_queue(p, k, next);
       else c.busy[k] = false;
-      comb_retire(done, ok ? REQ_DONE_OK : REQ_DONE_FAIL, first ? self : nullptr, wake);
+      comb_retire(p, done, ok ? REQ_DONE_OK : REQ_DONE_FAIL, first ? self : nullptr, wake);
     }
     comb_wake(wake);
     if (next.empty()) return self_ok;
@@ -295,8 +355,8 @@ bool comb_complete(StatePool *p, int k, PooledRef *self) {
     // one of the new group's own members waits for it: the first one that is still waiting for its frame
     for (const CombMember &e : next) {
       int expect = req_word(e.seq, REQ_INFLIGHT);
-      if (__atomic_compare_exchange_n(&e.ref->req, &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
-        if (__atomic_load_n(&e.ref->sleeping, __ATOMIC_SEQ_CST)) futex(&e.ref->req, FUTEX_WAKE_PRIVATE, 1);
+      if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) futex(&p->req[e.slot], FUTEX_WAKE_PRIVATE, 1);
         return self_ok;
       }
     }
@@ -312,13 +372,20 @@ bool comb_submit(StatePool *p, PooledRef *r) {
   // long for more requests to join its group -- fewer, larger groups, so that a stream is free more often when a request arrives
   static const uint64_t linger_ns = (uint64_t)std::max(0, env_int("RNNOISE_AMD_COMBINE_LINGER_US", 10)) * 1000ull;
   static const int spin_us = env_int("RNNOISE_AMD_COMBINE_SPIN_US", 400);
+  // A follower of a group has nothing to do until the group's frames come out, ~100-150 us later, and round 4 had it spin the whole
+  // time: at 16 threads that was 16 cores burning 2-3 x the CPU time the reference spends COMPUTING a frame.  Now it sleeps first --
+  // a timed futex wait on its request word for (the running estimate of a group's duration) minus $RNNOISE_AMD_COMBINE_WAKE_EARLY_US
+  // (40; measured 70 / 40 / 0 = spin from the start, 16 threads: 64 / 40 / 147 us of CPU per frame at 106 k / 109 k / 102 k frames/s,
+  // profiles/r5_configs0_cthreads.txt) -- and spins only for the rest.  A wake-up by the group's owner ends the sleep early.
+  static const int wake_early_us = env_int("RNNOISE_AMD_COMBINE_WAKE_EARLY_US", 40);
   struct Active {
     std::atomic<int> &a;
     explicit Active(std::atomic<int> &a_) : a(a_) { a.fetch_add(1, std::memory_order_relaxed); }
     ~Active() { a.fetch_sub(1, std::memory_order_relaxed); }
   } active(c.active);
-  r->seq = (uint32_t)(r->frame_no & 0x7fff) + 1u;
-  *done_word(r) = 0;
+  r->seq = (uint32_t)(r->req_no++ & 0x7fff) + 1u;  // (from the request counter, not the frame number: a retried frame is a new request)
+  int *const req = &p->req[r->slot], *const sleeping = &p->sleeping[r->slot];
+  *done_word(p, r->slot) = 0;
   const uint32_t seq = r->seq;
   // every way out with a frame: this caller is now "on its way back" (see the gather window below)
   auto leave = [&](bool ok) {
@@ -334,9 +401,15 @@ bool comb_submit(StatePool *p, PooledRef *r) {
     std::unique_lock<std::mutex> lk(c.mu);
     if (now_ns() - c.t_complete_ns.load(std::memory_order_relaxed) > gather_ns + 5000) c.pending_returns.store(0, std::memory_order_relaxed);  // stale
     else if (c.pending_returns.load(std::memory_order_relaxed) > 0) c.pending_returns.fetch_sub(1, std::memory_order_relaxed);
-    __atomic_store_n(&r->req, req_word(seq, REQ_QUEUED), __ATOMIC_SEQ_CST);
-    c.queue.push_back(CombMember{r, seq});
+    __atomic_store_n(req, req_word(seq, REQ_QUEUED), __ATOMIC_SEQ_CST);
+    c.queue.push_back(CombMember{r, r->slot, seq});
     int k = c.gathering ? -1 : comb_free_stream(p);
+    if (k < 0 && c.n_streams == 0) {
+      // not a single stream could be created: no group is in flight that could adopt this request, nobody would ever wake it
+      c.queue.pop_back();
+      __atomic_store_n(req, req_word(seq, REQ_IDLE), __ATOMIC_SEQ_CST);
+      return false;
+    }
     if (k >= 0 && c.pending_returns.load(std::memory_order_relaxed) > 0 && gather_ns) {
       // the other callers that have just got their frames are on their way back: hold the stream for them
       c.gathering = true;
@@ -360,9 +433,30 @@ bool comb_submit(StatePool *p, PooledRef *r) {
         k = comb_free_stream(p);
       }
     }
-    if (k >= 0 && __atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) {  // lead: the whole queue is this group
-      comb_take_queue(c, k, grp);
-      lead = k;
+    if (k >= 0 && __atomic_load_n(req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) {  // lead: the queue (its oldest 64 requests) is this group
+      comb_take_queue(p, k, grp);
+      bool mine = false;
+      for (const CombMember &e : grp) mine |= e.ref == r;
+      if (mine) lead = k;
+      else {  // (more than a row list's worth was queued in front of this request: launch that group, then wait like a follower)
+        lk.unlock();
+        if (comb_launch(p, k, grp)) comb_abort(p, k, grp, nullptr);
+        else {
+          // one of its members owns its wait; this thread goes on waiting for its own request
+          bool named = false;
+          for (const CombMember &e : grp) {
+            int expect = req_word(e.seq, REQ_INFLIGHT);
+            if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+              if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) futex(&p->req[e.slot], FUTEX_WAKE_PRIVATE, 1);
+              named = true;
+              break;
+            }
+          }
+          if (!named) (void)comb_complete(p, k, nullptr);
+        }
+        grp.clear();
+        lk.lock();
+      }
     }
   }
   if (lead >= 0) {
@@ -374,25 +468,38 @@ bool comb_submit(StatePool *p, PooledRef *r) {
   }
   // wait: for the frame (the row's `done` word, or the group's owner saying so), or to be named the owner of the group's wait
   const bool may_spin = c.active.load(std::memory_order_relaxed) <= effective_cpus();
+  if (wake_early_us > 0) {
+    const uint64_t est = c.group_ns.load(std::memory_order_relaxed);
+    if (est > (uint64_t)(wake_early_us + 20) * 1000ull) {
+      const uint64_t ns = est - (uint64_t)wake_early_us * 1000ull;
+      const int w = __atomic_load_n(req, __ATOMIC_SEQ_CST);
+      if ((w & 15) == REQ_QUEUED || (w & 15) == REQ_INFLIGHT) {
+        const timespec ts{(time_t)(ns / 1000000000ull), (long)(ns % 1000000000ull)};
+        __atomic_store_n(sleeping, 1, __ATOMIC_SEQ_CST);
+        if (__atomic_load_n(req, __ATOMIC_SEQ_CST) == w) syscall(SYS_futex, req, FUTEX_WAIT_PRIVATE, w, &ts, nullptr, 0);
+        __atomic_store_n(sleeping, 0, __ATOMIC_SEQ_CST);
+      }
+    }
+  }
   const uint64_t spin_until = now_ns() + (uint64_t)(may_spin ? spin_us : 20) * 1000ull;
   for (unsigned it = 0;; it++) {
-    const int w = __atomic_load_n(&r->req, __ATOMIC_SEQ_CST), s = w & 15;
+    const int w = __atomic_load_n(req, __ATOMIC_SEQ_CST), s = w & 15;
     if (s == REQ_SYNCER) return leave(comb_complete(p, r->grp, r));
     if (s == REQ_DONE_OK) return leave(true);
     if (s == REQ_DONE_FAIL) return false;
-    if (s == REQ_INFLIGHT && *done_word(r) == seq) {
+    if (s == REQ_INFLIGHT && *done_word(p, r->slot) == seq) {
       // the frame is out: say so (nobody may name this request its group's syncer any more) and go
       int expect = w;
-      if (__atomic_compare_exchange_n(&r->req, &expect, req_word(seq, REQ_DONE_OK), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return leave(true);
+      if (__atomic_compare_exchange_n(req, &expect, req_word(seq, REQ_DONE_OK), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return leave(true);
       continue;  // (named syncer, or retired, in between: look again)
     }
     if ((it & 63) != 63 || now_ns() < spin_until) {
       cpu_relax();
       continue;
     }
-    __atomic_store_n(&r->sleeping, 1, __ATOMIC_SEQ_CST);
-    if (__atomic_load_n(&r->req, __ATOMIC_SEQ_CST) == w) futex(&r->req, FUTEX_WAIT_PRIVATE, w);
-    __atomic_store_n(&r->sleeping, 0, __ATOMIC_SEQ_CST);
+    __atomic_store_n(sleeping, 1, __ATOMIC_SEQ_CST);
+    if (__atomic_load_n(req, __ATOMIC_SEQ_CST) == w) futex(req, FUTEX_WAIT_PRIVATE, w);
+    __atomic_store_n(sleeping, 0, __ATOMIC_SEQ_CST);
   }
 }
 
@@ -425,6 +532,8 @@ void pools_free(RNNModel *model) {
       hipHostFree(p->h_io);
       hipFree(p->d_flat);
     }
+    free(p->req);
+    free(p->sleeping);
     rnnoise_batch_destroy(p->batch);
     delete p;
   }
@@ -526,16 +635,28 @@ extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float
     if (!guard.ok) return frame_failed(out, "cannot select the HIP device");
     static const bool combine = [] { const char *e = getenv("RNNOISE_AMD_COMBINE"); return !e || atoi(e) != 0; }();
     float *h_in = r.h_io, *h_out = r.h_io + RN_FRAME_SIZE + 4;
+    if (__atomic_load_n(&r.poisoned, __ATOMIC_SEQ_CST)) {
+      // a launch group this state was part of failed after its high-pass may have run: the row's pitch ring and the host-side slot
+      // counters no longer agree.  Restart the stream from zero (what rnnoise_init leaves) rather than run it one ring slot off.
+      fprintf(stderr, "[rnnoise_amd] rnnoise_process_frame: the previous frame of this state failed on the GPU; its state restarts from zero\n");
+      if (pool_zero_row(r.pool, r.slot, nullptr) || hipStreamSynchronize(nullptr) != hipSuccess) return frame_failed(out, "cannot reset the state's row");
+      r.parity = r.ring_slot = 0;
+      r.frame_no = 0;
+      __atomic_store_n(&r.poisoned, 0, __ATOMIC_SEQ_CST);
+    }
     memcpy(h_in, in, RN_FRAME_SIZE * sizeof(float));
     bool ok;
-    if (combine) {
+    if (combine && !r.pool->comb.no_nn_one) {
       ok = comb_submit(r.pool, &r);
     } else {
       ok = (r.stream || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess) &&
            pool_step(r.pool, r.slot, r.parity, r.ring_slot, r.frame_no, h_out, h_in, h_out + RN_FRAME_SIZE, r.stream) == 0 &&
            hipStreamSynchronize(r.stream) == hipSuccess;
     }
-    if (!ok) return frame_failed(out, "GPU step failed");
+    if (!ok) {
+      __atomic_store_n(&r.poisoned, 1, __ATOMIC_SEQ_CST);  // (whichever path failed: the frame may be half in the row's state)
+      return frame_failed(out, "GPU step failed");
+    }
     r.parity = (r.parity + 1) % RN_SPEC_SLOTS;
     r.ring_slot = (r.ring_slot + 1) % RN_RING_SLOTS;
     r.frame_no++;
@@ -548,7 +669,7 @@ extern "C" float rnnoise_process_frame(DenoiseState *st, float *out, const float
   RNNModel *m = st->model;
   StatePool *pool = nullptr;
   int slot = -1;
-  if (pool_acquire(m, pool, slot)) return frame_failed(out, "no GPU state row available (no CPU fallback)");
+  if (pool_acquire(m, pool, slot, StatePool::FLAT_ROWS)) return frame_failed(out, "no GPU state row available (no CPU fallback)");
   struct Scratch {  // per-thread: a stream and a pinned staging block, created on first use, released at thread exit
     hipStream_t stream = nullptr;
     float *h = nullptr;

@@ -1594,8 +1594,8 @@ rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, Rn
   //  kernel 80 KB of code, more than the instruction cache two CUs share)
   const bool listed = rows.n > 0;
   const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
-  analysis_body<false, 1>(g, tb, listed ? (int)((re >> 8) & 7u) : slot, listed ? (int)((re >> 12) & 3u) : parity, RnTrainArgs{},
-                          listed ? (int)(re & 255u) : -1);
+  analysis_body<false, 1>(g, tb, listed ? RN_ROW_RING(re) : slot, listed ? RN_ROW_SPEC(re) : parity, RnTrainArgs{},
+                          listed ? RN_ROW_OF(re) : -1);
 }
 
 // A launch group of the one-frame API, for LATENCY: one workgroup of K1_SPW waves per listed row, every wave working on that
@@ -1606,7 +1606,7 @@ rn_analysis_single_kernel(RnGroupDev g, RnTablesDev tb, int slot, int parity, Rn
 extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rn_analysis_rows_kernel(RnGroupDev g, RnTablesDev tb, RnRows rows) {
   const uint32_t re = rows.e[blockIdx.x];
-  analysis_body<false, K1_SPW>(g, tb, (int)((re >> 8) & 7u), (int)((re >> 12) & 3u), RnTrainArgs{}, (int)(re & 255u));
+  analysis_body<false, K1_SPW>(g, tb, RN_ROW_RING(re), RN_ROW_SPEC(re), RnTrainArgs{}, RN_ROW_OF(re));
 }
 
 // TRAINING-mode variant: the inner loop of src/dump_features.c:466-491
@@ -1648,12 +1648,12 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
   // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
   const bool listed = rows.n > 0;  // a launch group of the one-frame API (rn_dev.h: RnRows)
   const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
-  const int parity = listed ? (int)((re >> 12) & 3u) : (parity_arg & 255);
+  const int parity = listed ? RN_ROW_SPEC(re) : (parity_arg & 255);
   const int prev = listed ? (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS : prev_arg;
   const bool out_s16 = !listed && (parity_arg & 256);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
-  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
+  const int s = listed ? RN_ROW_OF(re) : (int)blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
@@ -1820,7 +1820,7 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
     // completion word of the row's request (the last word of its pinned block): the caller waiting for this frame polls it
     // instead of waiting for the whole stream to drain.  System-scope release: the frame and the VAD are visible before it.
     __threadfence_system();
-    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(rows.io + (size_t)s * RN_ROW_IO + RN_ROW_IO - 1), re >> 16,
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(rows.io + (size_t)s * RN_ROW_IO + RN_ROW_IO - 1), RN_ROW_SEQ(re),
                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

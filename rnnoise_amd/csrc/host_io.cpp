@@ -231,29 +231,42 @@ static int batch_process_host_impl(RNNoiseBatch *b, void *out_v, const void *in_
     if (gains) memcpy(gains + (size_t)c * chunk * N * RN_NB_BANDS, io.h_gains[k], (size_t)f * N * RN_NB_BANDS * sizeof(float));
     return 0;
   };
-  if (upload(0)) return -1;
-  for (int c = 0; c < n_chunks; c++) {
-    const int k = c & 1, f = frames_of(c);
-    if (c + 1 < n_chunks && upload(c + 1)) return -1;
-    HIP_OK(hipStreamWaitEvent(io.run, io.up_done[k], 0));
-    if (c >= 2) HIP_OK(hipStreamWaitEvent(io.run, io.down_done[k], 0));  // d_out[k] of chunk c-2 has left
-    if (batch_process_device_impl(b, io.d_out[k], io.d_in[k], io.d_vad[k], io.d_gains[k], f, io.run, s16)) return -1;
-    HIP_OK(hipEventRecord(io.run_done[k], io.run));
-    if (!direct && c >= 2 && collect(c - 2)) return -1;  // frees h_out[k] for the download queued below
-    HIP_OK(hipStreamWaitEvent(io.down, io.run_done[k], 0));
-    void *dst_out = direct ? static_cast<void *>(out + (size_t)c * chunk * fsz) : io.h_out[k];
-    HIP_OK(hipMemcpyAsync(dst_out, io.d_out[k], (size_t)f * fsz, hipMemcpyDeviceToHost, io.down));
-    if (vad) HIP_OK(hipMemcpyAsync(direct ? vad + (size_t)c * chunk * N : io.h_vad[k], io.d_vad[k], (size_t)f * N * sizeof(float),
-                                   hipMemcpyDeviceToHost, io.down));
-    if (gains) HIP_OK(hipMemcpyAsync(direct ? gains + (size_t)c * chunk * N * RN_NB_BANDS : io.h_gains[k], io.d_gains[k],
-                                     (size_t)f * N * RN_NB_BANDS * sizeof(float), hipMemcpyDeviceToHost, io.down));
-    HIP_OK(hipEventRecord(io.down_done[k], io.down));
+  // the chunk loop as one unit: any failure inside it leaves copies and kernels in flight on three streams and the batch's frame
+  // bookkeeping out of step with what the GPU ran -- drain everything and put the batch back to its initial state, like the
+  // pinned path does
+  auto chunks = [&]() -> int {
+    if (upload(0)) return -1;
+    for (int c = 0; c < n_chunks; c++) {
+      const int k = c & 1, f = frames_of(c);
+      if (c + 1 < n_chunks && upload(c + 1)) return -1;
+      HIP_OK(hipStreamWaitEvent(io.run, io.up_done[k], 0));
+      if (c >= 2) HIP_OK(hipStreamWaitEvent(io.run, io.down_done[k], 0));  // d_out[k] of chunk c-2 has left
+      if (batch_process_device_impl(b, io.d_out[k], io.d_in[k], io.d_vad[k], io.d_gains[k], f, io.run, s16)) return -1;
+      HIP_OK(hipEventRecord(io.run_done[k], io.run));
+      if (!direct && c >= 2 && collect(c - 2)) return -1;  // frees h_out[k] for the download queued below
+      HIP_OK(hipStreamWaitEvent(io.down, io.run_done[k], 0));
+      void *dst_out = direct ? static_cast<void *>(out + (size_t)c * chunk * fsz) : io.h_out[k];
+      HIP_OK(hipMemcpyAsync(dst_out, io.d_out[k], (size_t)f * fsz, hipMemcpyDeviceToHost, io.down));
+      if (vad) HIP_OK(hipMemcpyAsync(direct ? vad + (size_t)c * chunk * N : io.h_vad[k], io.d_vad[k], (size_t)f * N * sizeof(float),
+                                     hipMemcpyDeviceToHost, io.down));
+      if (gains) HIP_OK(hipMemcpyAsync(direct ? gains + (size_t)c * chunk * N * RN_NB_BANDS : io.h_gains[k], io.d_gains[k],
+                                       (size_t)f * N * RN_NB_BANDS * sizeof(float), hipMemcpyDeviceToHost, io.down));
+      HIP_OK(hipEventRecord(io.down_done[k], io.down));
+    }
+    if (!direct)
+      for (int c = std::max(0, n_chunks - 2); c < n_chunks; c++)
+        if (collect(c)) return -1;
+    HIP_OK(hipStreamSynchronize(io.down));
+    HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
+    return 0;
+  };
+  if (chunks()) {
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: a GPU step or copy failed inside the call; the batch has been reset\n");
+    (void)rnnoise_batch_reset(b);
+    return -1;
   }
-  if (!direct)
-    for (int c = std::max(0, n_chunks - 2); c < n_chunks; c++)
-      if (collect(c)) return -1;
-  HIP_OK(hipStreamSynchronize(io.down));
-  HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
   return 0;
 }
 

@@ -183,7 +183,7 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
   // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
   const bool listed = rows.n > 0;
   const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
-  const int s = listed ? (int)(re & 255u) : (int)blockIdx.x, slot = listed ? (int)((re >> 8) & 7u) : slot_arg, lane = threadIdx.x;
+  const int s = listed ? RN_ROW_OF(re) : (int)blockIdx.x, slot = listed ? RN_ROW_RING(re) : slot_arg, lane = threadIdx.x;
   const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO : in + (size_t)s * RN_FRAME_SIZE;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;

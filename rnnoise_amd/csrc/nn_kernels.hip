@@ -307,7 +307,7 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
   NnLds &L = O.n;
   // (rows: a launch group of the one-frame API, rn_dev.h -- the block's pool row, its VAD goes to the row's pinned frame block)
   const bool listed = rows.n > 0;
-  const int s = listed ? (int)(rows.e[blockIdx.x] & 255u) : (int)blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int s = listed ? RN_ROW_OF(rows.e[blockIdx.x]) : (int)blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float *vad_dst = listed ? rows.io + (size_t)s * RN_ROW_IO + 2 * RN_FRAME_SIZE + 4 : g.vad + s;
   const bool chain_wave = t >= ONE_ROW_THREADS;  // waves 12 (dense_out) and 13 (vad_dense)
   const bool vad_wave = wave == 13;

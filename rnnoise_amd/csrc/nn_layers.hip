@@ -1,4 +1,4 @@
-// nn_layers.hip -- K2 for large batches (from 16,384 streams up, shim.cpp: nn_layers_min_streams): the network layer by layer.
+// nn_layers.hip -- K2 for large batches (from 16,384 streams up, batch.cpp: nn_layers_min_streams): the network layer by layer.
 //
 //   rn_nn_front_kernel (nn_mfma.hip)  conv1, conv2 per 16-stream tile; leaves the u8 image of the conv2 output in act_q[0]
 //   rn_nn_gru_kernel    x 3           one GRU layer (src/nnet.c:65-94) for 64 streams per workgroup
@@ -1284,7 +1284,7 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
 //   activations in the order the MFMA B operand wants, [input / 4][stream of the tile][input % 4] -- lane (n, gq) of step j
 //     reads word 64 j + 4 n + gq, the 64 lanes 64 consecutive words; a VAD lane reads its stream's 16 bytes of the same
 //     group; a DMA piece is 1 KB = 4 such groups, each lane fetching its 16 bytes from wherever its stream's row lives;
-//   dense_out weights in MFMA A-operand order (shim.cpp: stage_linear), one piece per row tile and group of four steps.
+//   dense_out weights in MFMA A-operand order (model.cpp: stage_linear), one piece per row tile and group of four steps.
 // No compiler-counted vector load is left in the loop: vmcnt retires in order, so a counted load issued behind a DMA piece
 // would make its consumer wait for that piece's HBM trip (first version: weights through a register ring, 132 us; the
 // chains stalled once per chunk).

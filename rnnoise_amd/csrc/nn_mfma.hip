@@ -3,7 +3,7 @@
 // streams.
 //
 //   int8 layers (conv2, 6 GRU matrices): v_mfma_i32_16x16x64_i8 on the block-sparse weights
-//     zero-filled to dense and pre-swizzled into A-fragment order (shim.cpp: stage_mfma), the
+//     zero-filled to dense and pre-swizzled into A-fragment order (model.cpp: stage_linear), the
 //     activations quantised exactly like the x86 path (u8, src/vec_avx.h:326-341) and
 //     re-centred to s8 = u8-128; acc_x86 = acc_mfma + 128*rowsum(w).  Integer => exact.
 //   float layers (conv1, dense_out): v_mfma_f32_16x16x4_f32, which on gfx950 is bitwise a

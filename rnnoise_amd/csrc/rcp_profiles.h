@@ -7,9 +7,9 @@
 //
 // Profiles:  "intel"     captured on the Intel Xeon build host (the committed goldens were produced there)
 //            "amd-zen5"  captured on the AMD EPYC 9575F hosts of the MI355X boxes
-//            "host"      captured at load time from the CPU the library runs on (shim.cpp: rcp_capture_host) -- the default:
+//            "host"      captured at load time from the CPU the library runs on (tables.cpp: rcp_select_locked) -- the default:
 //                        a process that swaps librnnoise.so.0 gets the bits the reference produced on that same machine.
-// Both the product (shim.cpp) and the oracle (oracle/rn_oracle.c) include this header; neither includes the other.
+// Both the product (tables.cpp) and the oracle (oracle/rn_oracle.c) include this header; neither includes the other.
 #pragma once
 #include "rcp_profile_intel.h"
 #include "rcp_profile_amd_zen5.h"

@@ -55,7 +55,7 @@ struct RnTablesDev {
   double dct_scale;           // sqrt(2./22), src/denoise.c:168
 };
 
-// one linear layer of the network, repacked for the GPU (shim.cpp: stage_linear)
+// one linear layer of the network, repacked for the GPU (model.cpp: stage_linear)
 struct RnLinearDev {
   const float *bias;      // float layers: bias; int8 layers: subias (x86 profile, nnet_arch.h:145-147)
   const float *fw;        // float weights, column-major W[j*N + i]
@@ -68,7 +68,7 @@ struct RnLinearDev {
   const int *rowsum128;   // 128 * sum_j w[i][j]  (offset that turns s8 x s8 dots into s8 x u8)
   const int *grp_start;   // [nout/8 + 1] first block of each 8-row group
   const uint16_t *cols;   // [nblocks] first input column of each block
-  // the same int8 weights once more, row-major for the vector path (shim.cpp: model_on_device): a row's bytes of FOUR
+  // the same int8 weights once more, row-major for the vector path (model.cpp: model_on_device): a row's bytes of FOUR
   // consecutive blocks of its group are one 16-byte chunk, a group's list padded with zero blocks to a multiple of four --
   //   wrow [(((grp4[g] + c) * 8 + (row & 7)) * 4 .. + 3]       chunk c of a row of group g (grp4[g+1] - grp4[g] chunks; the eight
   //                                                            rows' chunks c are one 128-byte line)
@@ -125,15 +125,23 @@ struct RnGroupDev {
   float *debug;        // [N][RN_DBG_FLOATS] pitch stage taps, or null (tests only)
 };
 
-// Row list of the one-frame API (shim: the combiner behind rnnoise_process_frame).  Concurrent rnnoise_process_frame calls on
+// Row list of the one-frame API (dropin.cpp: the combiner behind rnnoise_process_frame).  Concurrent rnnoise_process_frame calls on
 // states of one pool are gathered into ONE launch group: block b of the latency kernels (rn_hp_one_kernel,
-// rn_analysis_single_kernel, rn_nn_one_kernel, rn_synthesis_kernel) then works on pool row e[b] & 255 at that row's own
-// frame phase -- ring slot (e[b] >> 8) & 7, spectra slot (e[b] >> 12) & 3 -- and exchanges the frame through the row's block
+// rn_analysis_rows_kernel, rn_nn_one_kernel, rn_synthesis_few_kernel) then works on pool row RN_ROW_OF(e[b]) at that row's own
+// frame phase -- ring slot RN_ROW_RING(e[b]), spectra slot RN_ROW_SPEC(e[b]) -- and exchanges the frame through the row's block
 // of the pool's pinned host memory: io + row * RN_ROW_IO = in[480] | pad[4] | out[480] | vad | pad[2] | done, where the last
-// kernel of the group stores the request's sequence number e[b] >> 16 into `done` once frame and VAD are out.  n == 0: no list --
-// block b is stream b of the group and the launch's own arguments apply (every batched call).  Passed by value: the list
+// kernel of the group stores the request's sequence number RN_ROW_SEQ(e[b]) into `done` once frame and VAD are out.  n == 0: no
+// list -- block b is stream b of the group and the launch's own arguments apply (every batched call).  Passed by value: the list
 // rides in the kernel arguments, so a group costs no copy and no extra memory round trip.
+// A list has at most RN_ROWS_MAX entries; a pool has up to RN_POOL_ROWS_MAX rows (round 5: 1024 instead of 64, so that a thousand
+// states share ONE combiner and its three streams instead of opening a pool -- and three streams -- per 64).
 #define RN_ROWS_MAX 64
+#define RN_POOL_ROWS_MAX 1024
+#define RN_ROW_ENTRY(row, ring, spec, seq) ((uint32_t)(row) | (uint32_t)(ring) << 10 | (uint32_t)(spec) << 13 | (uint32_t)(seq) << 16)
+#define RN_ROW_OF(e) ((int)((e) & 1023u))
+#define RN_ROW_RING(e) ((int)(((e) >> 10) & 7u))
+#define RN_ROW_SPEC(e) ((int)(((e) >> 13) & 3u))
+#define RN_ROW_SEQ(e) ((e) >> 16)
 #define RN_ROW_IO 968
 struct RnRows {
   float *io;

@@ -199,9 +199,10 @@ struct PooledRef;
 // groups -- ONE set of the four latency kernels over a row list (rn_dev.h: RnRows) per group, a few groups in flight on streams
 // of their own.
 struct CombMember {
-  PooledRef *ref;
-  uint32_t seq;  // the request of `ref` this entry stands for (a state that has its frame may be back with the next one
-                 // before the group's owner has retired the old entry)
+  PooledRef *ref;  // dereferenced only while the request is queued or being launched (its caller is blocked then); afterwards an identity
+  int slot;        // the state's row: its request / sleeping / done words are the pool's (StatePool::req ...), valid whatever the state does
+  uint32_t seq;    // the request of `ref` this entry stands for (a state that has its frame may be back with the next one
+                   // before the group's owner has retired the old entry)
 };
 struct Combiner {
   static constexpr int MAXG = 8;
@@ -215,20 +216,31 @@ struct Combiner {
   std::atomic<int> pending_returns{0};     // callers that have just got their frame and have not come back with the next one yet
   std::atomic<uint64_t> t_complete_ns{0};  // ... when the last of them left
   std::atomic<int> active{0};              // threads inside rnnoise_process_frame on this pool right now (spin or sleep?)
+  std::atomic<uint64_t> group_ns{0};       // running estimate of a group's launch -> frames-out time (followers sleep through most of it)
+  bool no_nn_one = false;                  // the latency network kernel cannot run here (LDS opt-in refused, $RNNOISE_AMD_NN_ONE_MAX=0):
+                                           // frames go one state at a time through pool_step instead of through launch groups
 };
 
 // A pool of device-resident one-stream states of one model on one device: the arrays of a POOL_SLOTS-stream batch, of
 // which every rnnoise_create() owns one row, and one block of pinned host memory per row through which the row's frames
 // travel (the kernels address it directly: no copy commands).
 struct StatePool {
-  static constexpr int POOL_SLOTS = RN_ROWS_MAX;
+  // rows of a pool: $RNNOISE_AMD_POOL_ROWS (default and maximum RN_POOL_ROWS_MAX = 1024, at least 64; 27 KB of HBM and 3.9 KB of
+  // pinned host memory per row).  Round 4 had 64 = one launch group's worth, so the 65th state opened a second pool with a combiner
+  // and three streams of its own -- 64 threads over 256 / 1,024 states: 152 k / 30 k frames/s against 304 k / 132 k with 256 rows.
+  int rows = 0;
   RNNoiseBatch *batch = nullptr;   // owns the arena; never processed as a whole
   static constexpr int FLAT_IO = RN_STATE_FLOATS + 2;           // frame offset inside a staging block (16-byte aligned)
   static constexpr int FLAT_BLK = FLAT_IO + RN_FRAME_SIZE + 4;  // state | pad | frame (in, then out in place) | vad | pad
-  float *h_io = nullptr;           // pinned [POOL_SLOTS][RN_ROW_IO]: in[480] | pad[4] | out[480] | vad | pad[3] (rn_dev.h: RnRows)
-  float *d_flat = nullptr;         // [POOL_SLOTS][FLAT_BLK] staging for self-contained states (rnnoise_init path)
+  static constexpr int FLAT_ROWS = 64;                          // staging blocks (rnnoise_init states borrow rows 0 .. 63 only)
+  float *h_io = nullptr;           // pinned [rows][RN_ROW_IO]: in[480] | pad[4] | out[480] | vad | pad[2] | done (rn_dev.h: RnRows)
+  float *d_flat = nullptr;         // [FLAT_ROWS][FLAT_BLK] staging for self-contained states (rnnoise_init path)
   std::mutex mu;
-  unsigned long long used = 0;     // bit per slot
+  std::vector<unsigned long long> used;  // bit per row
+  // combiner words of the rows' requests.  They live HERE, not in the state (PooledRef), because a group's owner touches a
+  // member's words after the member may have taken its frame and been destroyed: pool memory outlives every state of the pool
+  int *req = nullptr;        // [rows] (sequence number << 4 | state) of the row's request in flight (atomic access; futex word)
+  int *sleeping = nullptr;   // [rows] the row's caller sleeps on req[row] (atomic access)
   Combiner comb;
 };
 
@@ -242,10 +254,12 @@ struct PooledRef {
   float *h_io;        // the row's block of the pool's pinned frame memory
   std::mutex *mu;     // one frame at a time per state (the reference's states are not re-entrant either)
   hipStream_t stream; // only when the combiner is switched off ($RNNOISE_AMD_COMBINE=0): the state's own stream
-  int req;            // combiner: (sequence number << 4 | state) of the request in flight (atomic access; futex word)
-  int sleeping;       // combiner: the owner sleeps on `req` (atomic access)
   int grp;            // combiner: stream slot of the group the request went into
   uint32_t seq;       // combiner: sequence number of the request (never 0); the last kernel stores it into the row's `done` word
+  uint32_t req_no;    // combiner: requests made so far, failed ones included (the sequence numbers come from here, so that a retried
+                      //           frame is never mistaken for the failed request)
+  int poisoned;       // a launch group this state was in failed part of the way: its pitch ring may already hold the frame.  The
+                      //           next call restarts the state from zero (as rnnoise_init would) instead of running one slot off
 };
 
 struct DenoiseState {

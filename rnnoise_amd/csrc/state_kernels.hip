@@ -75,7 +75,7 @@ extern "C" hipError_t rn_launch_state_scatter(const RnGroupDev *g, const float *
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device -> pinned-host copy by a SMALL kernel (host-fed path, shim.cpp: batch_process_pinned).  hipMemcpyAsync finds the
+// Device -> pinned-host copy by a SMALL kernel (host-fed path, host_io.cpp: batch_process_pinned).  hipMemcpyAsync finds the
 // DMA engine busy with the upload running the other way and falls back to the runtime's blit kernel -- 256 workgroups of
 // 512 lanes whose PCIe-bound stores fill the memory pipeline of every CU: the analysis kernel running beside it takes
 // 2.3 ms instead of 1.1 (rocprofv3 trace).  Posted writes over PCIe need few lanes to fill the link, so this copy runs on

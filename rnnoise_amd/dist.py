@@ -27,12 +27,12 @@ def aggregate_throughput(frames: float, elapsed: float, dist=None, device=None):
     return float(f.item()), float(t.item())
 
 
-def aggregate_times(times, dist=None, device=None):
-    """Element-wise MAX over ranks of a list of per-repetition elapsed times (one all-reduce)."""
+def aggregate_times(times, dist=None, device=None, group=None):
+    """Element-wise MAX over ranks of a list of per-repetition elapsed times (one all-reduce on `group`, default: the job's)."""
     times = [float(t) for t in times]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return times
     import torch
     t = torch.tensor(times, dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return [float(v) for v in t.tolist()]

@@ -48,3 +48,21 @@ def test_without_a_gpu_the_real_path_refuses_loudly():
     if torch.cuda.is_available():
         return
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+def test_a_rank_without_a_working_data_communicator_sends_the_job_to_gloo():
+    """the 8-GPU run's first collective must not be able to kill or hang it: every rank tries the data group once and votes
+    over the gloo control group; one failing rank (injected here) -> "collective": "gloo-fallback", the line still comes out"""
+    args = ["--gpus", "2", "--stub", "--streams", "64", "--smoke"]
+    ok = _run(args, {"RNNOISE_AMD_BENCH_DATA_BACKEND": "gloo"})
+    assert ok.returncode == 0, ok.stdout[-2000:] + ok.stderr[-3000:]
+    d = json.loads([l for l in ok.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["collective"] == "gloo" and "collective_error" not in d
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["repeats"] == 1          # --smoke
+    assert len(d["value_by_rank"]) == 2 and all(v > 0 for v in d["value_by_rank"])
+    assert d["value"] <= sum(d["value_by_rank"]) * 1.001                        # the aggregate is paced by the slowest rank
+    bad = _run(args, {"RNNOISE_AMD_BENCH_DATA_BACKEND": "gloo", "RNNOISE_AMD_BENCH_BREAK_RCCL": "1", "RNNOISE_AMD_BENCH_DATA_TIMEOUT": "8"})
+    assert bad.returncode == 0, bad.stdout[-2000:] + bad.stderr[-3000:]
+    d = json.loads([l for l in bad.stdout.splitlines() if l.startswith("{")][-1])
+    # (the error quoted is the first in rank order: rank 0's time-out waiting for rank 1, whose communicator "failed")
+    assert d["collective"] == "gloo-fallback" and d["collective_error"].startswith("rank ") and d["n_gpus"] == 2

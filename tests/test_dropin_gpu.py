@@ -26,7 +26,7 @@ def model(blob_default):
 
 @pytest.mark.parametrize("n_threads", [4, 32])
 def test_pooled_states_on_four_threads(model, blob_default, n_threads):
-    """70 rnnoise_create()d states (more than one 64-row pool), driven from 4 and from 32 threads at once: every stream gets the
+    """70 rnnoise_create()d states (more than a launch group's 64 entries), driven from 4 and from 32 threads at once: every stream gets the
     oracle's bits -- states are independent, no global lock serialises them into one another's data, and the combiner that
     gathers concurrent calls into shared launches (dropin.cpp) keeps every row at its own frame phase: state s starts s % 4
     frames late, so the rows of one launch group sit at different ring and spectra slots"""
@@ -66,6 +66,74 @@ def test_pooled_states_on_four_threads(model, blob_default, n_threads):
     st = capi.DenoiseState(model)
     y, v = st.process_frame(pcm[3][0])
     assert_bits_equal(y, Oracle(blob_default).run(pcm[3][:1])["out"][0], "first frame of a recycled row")
+
+
+def test_three_hundred_states_from_ninety_six_threads(model, blob_default):
+    """more states than a pool has rows (256 by default: the 257th opens a second pool, on the next device if there is one) and
+    more concurrent callers than a launch group has entries (64): the combiner launches the oldest 64 queued requests and leaves
+    the rest for the next group; rows sit at staggered frame phases; every stream gets the oracle's bits"""
+    T, n, n_threads = 6, 300, 96
+    pcm = [synth.stream_pcm(s % 7, T, lead_silence=s % 2).astype(np.float32).reshape(T, 480) for s in range(n)]
+    want = {}
+    for s in range(n):
+        if (s % 7, s % 2) not in want:
+            want[(s % 7, s % 2)] = Oracle(blob_default).run(pcm[s])
+    states = [capi.DenoiseState(model) for _ in range(n)]
+    got_out = [np.zeros((T, 480), np.float32) for _ in range(n)]
+    got_vad = [np.zeros(T, np.float32) for _ in range(n)]
+    errs = []
+
+    def work(tid):
+        try:
+            for t in range(T + 2):
+                for s in range(tid, n, n_threads):
+                    f = t - s % 3
+                    if 0 <= f < T:
+                        got_out[s][f], got_vad[s][f] = states[s].process_frame(pcm[s][f])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for s in range(n):
+        ref = want[(s % 7, s % 2)]
+        assert_bits_equal(got_out[s], ref["out"], f"pcm of state {s}")
+        assert_bits_equal(got_vad[s], ref["vad"], f"vad of state {s}")
+    for st in states:
+        st.close()
+
+
+def test_batch_and_pooled_state_on_the_last_device(blob_default):
+    """a node with several GPUs: a batch created on the LAST device, and a process whose rnnoise_create() states are sent there
+    ($RNNOISE_AMD_DEVICE), give the oracle's bits -- device 0 is not special.  (One GPU: skipped; the 8-GPU run is the driver's.)"""
+    n_dev = capi.lib().rnnoise_amd_device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU visible")
+    T = 6
+    pcm = synth.batch_pcm(range(40), T, lead_silence=1)
+    want = oracle_run(blob_default, pcm, collect_state=False)
+    m = capi.Model(blob_default)
+    b = capi.Batch(m, 40, device=n_dev - 1)
+    out, vad, gains = b.process(pcm)
+    assert_bits_equal(out, want["out"], "pcm on the last device")
+    assert_bits_equal(gains, want["gains"], "gains on the last device")
+    b.close()
+    code = r"""
+import sys, zlib, lzma, numpy as np
+sys.path.insert(0, %r)
+from rnnoise_amd import capi, synth
+m = capi.Model(lzma.decompress(open(%r, "rb").read()))
+st = [capi.DenoiseState(m) for _ in range(3)]
+x = synth.batch_pcm(range(3), 6, lead_silence=1)
+y = np.stack([np.stack([st[s].process_frame(x[t, s])[0] for s in range(3)]) for t in range(6)])
+print("CRC", zlib.crc32(y.tobytes()))
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "default.blob.xz"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, RNNOISE_AMD_DEVICE=str(n_dev - 1)), timeout=300)
+    import zlib
+    assert r.returncode == 0 and f"CRC {zlib.crc32(np.ascontiguousarray(want['out'][:, :3]).tobytes())}" in r.stdout, r.stdout + r.stderr
 
 
 def test_caller_memory_states_interleaved(model, blob_default):

@@ -1,43 +1,62 @@
-/* BASELINE configs[0] through the drop-in API from plain C threads (no Python in the loop): T threads, each with its own
- * rnnoise_create() state, F frames each after a warm-up.  Build (no hipcc needed):
+/* BASELINE configs[0] through the drop-in API from plain C threads (no Python in the loop): T threads share S rnnoise_create()
+ * states (S >= T; thread i walks over states i, i + T, ... round-robin, a frame at a time: a server with more streams than
+ * threads), F frames per STATE after a warm-up.  Reports frames/s and the CPU time the process spent per frame (getrusage:
+ * user + system, every thread) -- a synchronous caller that spins while the GPU works burns a core per thread.
+ * Build (no hipcc needed):
  *   gcc -O2 -Iinclude tools/configs0_mt.c -o /tmp/configs0_mt -Lrnnoise_amd -l:librnnoise_amd.so -Wl,-rpath,$PWD/rnnoise_amd -lpthread
- * usage: configs0_mt weights_blob.bin [threads = 4] [frames = 2000] */
+ * usage: configs0_mt weights_blob.bin [threads = 4] [frames per state = 2000] [states = threads] */
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/resource.h>
 #include <time.h>
 #include "rnnoise.h"
 
+#define MAXT 256
 static RNNModel *model;
-static int frames;
+static int frames, T, S;
+static DenoiseState **states;
 static void *worker(void *arg) {
-  DenoiseState *st = rnnoise_create(model);
+  const int me = (int)(size_t)arg;
   float x[480];
-  unsigned s = 12345u + (unsigned)(size_t)arg;
-  for (int t = 0; t < frames + 100; t++) {
-    for (int i = 0; i < 480; i++) { s = s * 1664525u + 1013904223u; x[i] = (float)((int)(s >> 18) - 8192); }
-    rnnoise_process_frame(st, x, x);
-    if (t == 99) *(double *)arg = 0;  /* (warm-up done; the caller times the whole run, warm-up included in both numerator and denominator) */
-  }
-  rnnoise_destroy(st);
+  unsigned s = 12345u + (unsigned)me;
+  for (int t = 0; t < frames + 100; t++)
+    for (int k = me; k < S; k += T) {
+      for (int i = 0; i < 480; i++) { s = s * 1664525u + 1013904223u; x[i] = (float)((int)(s >> 18) - 8192); }
+      rnnoise_process_frame(states[k], x, x);
+    }
   return NULL;
+}
+static double cpu_seconds(void) {
+  struct rusage u;
+  getrusage(RUSAGE_SELF, &u);
+  return u.ru_utime.tv_sec + u.ru_stime.tv_sec + 1e-6 * (u.ru_utime.tv_usec + u.ru_stime.tv_usec);
 }
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
-  const int T = argc > 2 ? atoi(argv[2]) : 4;
+  T = argc > 2 ? atoi(argv[2]) : 4;
   frames = argc > 3 ? atoi(argv[3]) : 2000;
+  S = argc > 4 ? atoi(argv[4]) : T;
+  if (T < 1 || T > MAXT || S < T) { fprintf(stderr, "threads 1..%d, states >= threads\n", MAXT); return 2; }
   model = rnnoise_model_from_filename(argv[1]);
   if (!model) { fprintf(stderr, "cannot load %s\n", argv[1]); return 1; }
-  { DenoiseState *w = rnnoise_create(model); float x[480] = {0}; for (int i = 0; i < 50; i++) rnnoise_process_frame(w, x, x); rnnoise_destroy(w); }
-  pthread_t th[64];
-  double slot[64];
+  states = calloc((size_t)S, sizeof *states);
+  for (int k = 0; k < S; k++)
+    if (!(states[k] = rnnoise_create(model))) { fprintf(stderr, "rnnoise_create failed at state %d\n", k); return 1; }
+  { float x[480] = {0}; for (int i = 0; i < 50; i++) rnnoise_process_frame(states[0], x, x); }
+  pthread_t th[MAXT];
   struct timespec a, b;
+  const double c0 = cpu_seconds();
   clock_gettime(CLOCK_MONOTONIC, &a);
-  for (int i = 0; i < T; i++) pthread_create(&th[i], NULL, worker, &slot[i]);
+  for (int i = 0; i < T; i++) pthread_create(&th[i], NULL, worker, (void *)(size_t)i);
   for (int i = 0; i < T; i++) pthread_join(th[i], NULL);
   clock_gettime(CLOCK_MONOTONIC, &b);
-  const double dt = (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec), n = (double)T * (frames + 100);
-  printf("configs[0] C threads: %d x %d frames in %.3f s = %.0f frames/s (%.1f us per frame per thread)\n", T, frames + 100, dt, n / dt, 1e6 * dt / (frames + 100));
+  const double c1 = cpu_seconds();
+  const double dt = (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec), n = (double)S * (frames + 100);
+  printf("configs[0] C threads: %3d threads, %4d states x %d frames in %.3f s = %7.0f frames/s (%.1f us per frame per thread); CPU %.1f us per frame (%.1f cores busy)\n",
+         T, S, frames + 100, dt, n / dt, 1e6 * dt * T / n, 1e6 * (c1 - c0) / n, (c1 - c0) / dt);
+  for (int k = 0; k < S; k++) rnnoise_destroy(states[k]);
+  free(states);
   rnnoise_model_free(model);
   return 0;
 }
