@@ -112,7 +112,7 @@ def waves_per_launch(kind: str, n_streams: int, nn: str = "mfma") -> int:
 def valu_cost(kernel: str) -> float:
     """Mean clocks per wave64 VALU instruction per SIMD of `kernel`: its instruction mix (tools/valu_mix.py over the built
     objects -> profiles/valu_mix.json) priced with the per-instruction issue costs MEASURED on the MI355X
-    (profiles/r3_valu_issue.txt: 2.26 clk for plain f32/u32 VOP2 forms, 4.15 for DPP / SGPR-source / packed / f64 / compare /
+    (profiles/r4_valu_issue.txt: 2.26 clk for plain f32/u32 VOP2 forms, 4.15 for DPP / SGPR-source / packed / f64 / compare /
     select / convert / 3-operand forms, 8.12 for transcendentals and v_permlane32_swap).  MI355X_MICROARCH.md's "2 cycles per
     wave64 v_fma_f32" holds for the first class only; the PMC ratio 4*SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU (4.0 for every
     kernel) is a property of the counter.  4.15 when the kernel has no record."""
@@ -612,7 +612,7 @@ def bench_rank(a) -> dict | None:
                 ti = pa["valu_per_wave"] * wa * valu_cost(pa.get("kernel", na)) / N_SIMD / clock_hz(pa)
                 line["roofline_standalone"]["valu_issue_frac"] = round(ti / (da_ms * 1e-3), 4)
                 line["roofline_standalone"]["valu_note"] = (f"{pa['valu_per_wave']} VALU instructions per wave (PMC) x "
-                                                           f"{valu_cost(pa.get('kernel', na)):.2f} clk (instruction mix priced with profiles/r3_valu_issue.txt) "
+                                                           f"{valu_cost(pa.get('kernel', na)):.2f} clk (instruction mix priced with profiles/r4_valu_issue.txt) "
                                                            f"over 1024 SIMDs at {clock_hz(pa) / 1e9:.2f} GHz")
                 line["roofline_standalone"]["clock_ghz"] = round(clock_hz(pa) / 1e9, 3)
             if "lds_cycles_per_wave" in pa:
@@ -633,7 +633,7 @@ def bench_rank(a) -> dict | None:
                                      "frac": round(t_issue / (dom_ms * 1e-3), 4),
                                      "frac_f32_peak": round(t_issue * VALU_FLOOR / cpi / (dom_ms * 1e-3), 4),
                                      "peak": "1024 SIMDs x clock_ghz / clocks_per_inst wave64 instructions/s; clocks_per_inst = this kernel's "
-                                             "instruction mix priced with the per-instruction costs measured in profiles/r3_valu_issue.txt "
+                                             "instruction mix priced with the per-instruction costs measured in profiles/r4_valu_issue.txt "
                                              "(frac_f32_peak: every instruction at 2.26 clk, the measured plain-f32 rate)",
                                      "source": pmc.get("source", "profiles/")}
         if "lds_cycles_per_wave" in pmc and dom_ms > 0:
@@ -652,7 +652,7 @@ def bench_rank(a) -> dict | None:
                                               "frac": round(vi / (1e3 * med / K), 4),
                                               "definition": "sum over the step's kernels of waves x VALU instructions per wave (PMC passes under "
                                                             "profiles/) x that kernel's mix-priced clocks per instruction (profiles/valu_mix.json, "
-                                                            "profiles/r3_valu_issue.txt), over 1024 SIMDs at each kernel's measured clock, divided by ms_per_step"}
+                                                            "profiles/r4_valu_issue.txt), over 1024 SIMDs at each kernel's measured clock, divided by ms_per_step"}
         except Exception:
             pass
         if stub:

@@ -70,8 +70,10 @@ def test_65536_stream_batch_properties(blob_default, rcp_profile):
     _tiled_check(blob_default, 65536, (5, 1, 8), silent_stream=21)
 
 
-def test_sparser_model_32768(blob_little):
-    """BASELINE configs[3]: the sparser blob at 32,768 streams, 14 frames as calls of 5 + 1 + 8"""
+@pytest.mark.parametrize("rcp_profile", ["intel", "host"], indirect=True)
+def test_sparser_model_32768(blob_little, rcp_profile):
+    """BASELINE configs[3]: the sparser blob at 32,768 streams, 14 frames as calls of 5 + 1 + 8 -- on the goldens' profile and on
+    the profile a deployed process runs on (this machine's rcpps)"""
     _tiled_check(blob_little, 32768, (5, 1, 8), silent_stream=9)
 
 

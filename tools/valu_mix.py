@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mean issue cost of a kernel's VALU instructions, from its disassembly and the measured per-instruction table.
 
-profiles/r3_valu_issue.txt (rnnoise_amd/csrc/tools/valu_issue.hip, run on the MI355X) shows that a wave64 VALU instruction
+profiles/r4_valu_issue.txt (rnnoise_amd/csrc/tools/valu_issue.hip, run on the MI355X) shows that a wave64 VALU instruction
 does NOT have one cost on gfx950: with two or more waves on a SIMD the plain f32 / u32 VOP2 forms issue every ~2.2-2.3 clocks,
 anything with a DPP / SDWA modifier, an SGPR source, a packed, f64, integer-multiply, compare, select, convert or 3-operand
 form every ~4.1, transcendentals and v_permlane32_swap every ~8.1.  The PMC ratio 4*SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU is
@@ -24,7 +24,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-# clocks per wave64 instruction per SIMD at >= 2 waves/SIMD ("B" column, 4 waves/SIMD) of profiles/r3_valu_issue.txt
+# clocks per wave64 instruction per SIMD at >= 2 waves/SIMD ("B" column, 4 waves/SIMD) of profiles/r4_valu_issue.txt
 COST = {"fast": 2.26, "std": 4.15, "trans": 8.12}
 FAST = {"v_fma_f32", "v_fmac_f32", "v_add_f32", "v_mul_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_and_b32", "v_xor_b32",
         "v_or_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32"}
@@ -163,12 +163,12 @@ def main():
             r["valu_dynamic_per_wave"] = d["valu_dynamic_per_wave"]
             r["sections"] = d["sections"]
     print(f"# mean VALU issue cost per kernel from the static instruction mix; classes: fast {COST['fast']} clk (plain f32/u32 VOP2, no SGPR "
-          f"source), std {COST['std']} clk, trans {COST['trans']} clk  [profiles/r3_valu_issue.txt, >= 2 waves per SIMD]")
+          f"source), std {COST['std']} clk, trans {COST['trans']} clk  [profiles/r4_valu_issue.txt, >= 2 waves per SIMD]")
     print(f"{'kernel':<30}{'VALU':>7}{'fast':>7}{'std':>7}{'trans':>7}{'MFMA':>7}{'sel(vcc)':>9}{'mean clk':>10}")
     for k, r in sorted(res.items()):
         print(f"{k:<30}{r['valu_static']:>7}{r['fast']:>7}{r['std']:>7}{r['trans']:>7}{r['mfma_static']:>7}{r['select_on_vcc']:>9}{r['mean_cycles']:>10.2f}")
     if jpath:
-        json.dump({"source": "tools/valu_mix.py over rnnoise_amd/csrc/build/*.o; costs from profiles/r3_valu_issue.txt", "cost": COST,
+        json.dump({"source": "tools/valu_mix.py over rnnoise_amd/csrc/build/*.o; costs from profiles/r4_valu_issue.txt", "cost": COST,
                    "kernels": res}, open(jpath, "w"), indent=1)
 
 
