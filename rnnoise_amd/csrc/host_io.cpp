@@ -2,6 +2,10 @@
 // device call, pageable memory through double-buffered bounce chunks.
 #include "shim.h"
 
+#include <hsa/amd_hsa_signal.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
 // ---- host-fed path (pinned, double-buffered H2D / D2H) ----
 namespace {
 bool host_pinned(const void *p) {  // memory the DMA engines can reach directly (hipHostMalloc / hipHostRegister)
@@ -14,8 +18,103 @@ bool host_pinned(const void *p) {  // memory the DMA engines can reach directly 
 }
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------
+// Copy mode "sdma": the two PCIe directions on two NAMED copy engines, at once.
+// HIP picks the engine of a hipMemcpyAsync itself, and with an upload and a download in flight it runs one of them as a blit kernel
+// whose PCIe-bound stores stall the kernels beside it (profiles/r3_hostio_traces.txt) -- which is why the other modes move an int16
+// frame's 2 x 63 MB one direction at a time.  Underneath HIP, ROCr takes copies for a named engine
+// (hsa_amd_memory_async_copy_on_engine); what it does not have is HIP's stream ordering, so the three cross-dependencies of the
+// frame ring are built from pieces that profiles/r5_sdma_probe.txt shows working on this runtime:
+//   copy engine -> stream  a second, 8-byte copy queued behind the payload on the same engine writes the running count of landed
+//                          frames into a word of device memory; the stream waits for it with hipStreamWaitValue64;
+//   stream -> copy engine  a one-thread kernel on the stream stores 0 (system-scope release) into the value word of an HSA signal that
+//                          the copy lists as its dependency (rn_release_store_kernel);
+//   copy engine -> host    the completion signal of the call's last copy (hsa_signal_wait).
+// ---------------------------------------------------------------------------------------------
+struct Sdma {
+  bool ok = false;
+  hsa_agent_t gpu{}, cpu{};
+  hsa_amd_sdma_engine_id_t e_up{}, e_dn{};
+  uint64_t *d_flags = nullptr;  // device memory: [0] uploads landed so far, [32] downloads landed so far (separate lines)
+  uint64_t *h_seq = nullptr;    // pinned [SEQ]: the source words of the count copies
+  static constexpr int SEQ = 2048;
+  uint64_t up_count = 0, dn_count = 0;
+  std::vector<hsa_signal_t> pool;
+  size_t used = 0;
+  hsa_signal_t take(hsa_signal_value_t v) {
+    if (used == pool.size()) {
+      hsa_signal_t s{};
+      if (hsa_signal_create(v, 0, nullptr, &s) != HSA_STATUS_SUCCESS) return hsa_signal_t{0};
+      pool.push_back(s);
+    }
+    hsa_signal_t s = pool[used++];
+    hsa_signal_store_relaxed(s, v);
+    return s;
+  }
+};
+
+namespace {
+bool sdma_owner(const void *p, hsa_agent_t &agent, const void *&agent_ptr) {  // who owns p, and p as that side's engines address it
+  hsa_amd_pointer_info_t info;
+  memset(&info, 0, sizeof info);
+  info.size = sizeof info;
+  if (hsa_amd_pointer_info(p, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+  agent = info.agentOwner;
+  agent_ptr = p;
+  if (info.type == HSA_EXT_POINTER_TYPE_LOCKED && info.hostBaseAddress && info.agentBaseAddress)  // hipHostRegister-ed memory
+    agent_ptr = static_cast<const char *>(info.agentBaseAddress) + (static_cast<const char *>(p) - static_cast<const char *>(info.hostBaseAddress));
+  return true;
+}
+Sdma *sdma_get(RNNoiseBatch *b, const void *host_ptr) {
+  RNNoiseBatch::HostIo &io = b->io;
+  if (io.sdma) return io.sdma->ok ? io.sdma : nullptr;
+  Sdma *s = io.sdma = new Sdma();
+  auto fail = [&](const char *what, hsa_status_t st) -> Sdma * {
+    const char *m = nullptr;
+    hsa_status_string(st, &m);
+    fprintf(stderr, "[rnnoise_amd] copy mode sdma unavailable (%s: %s); using the runtime's copies\n", what, m ? m : "?");
+    return nullptr;
+  };
+  hsa_status_t st = hsa_init();  // (reference-counted; the HIP runtime holds the first reference)
+  if (st != HSA_STATUS_SUCCESS) return fail("hsa_init", st);
+  const void *ap = nullptr;
+  if (!sdma_owner(io.ring_mem, s->gpu, ap) || !sdma_owner(host_ptr, s->cpu, ap)) return fail("hsa_amd_pointer_info", HSA_STATUS_ERROR);
+  uint32_t free_up = 0, free_dn = 0, pref_up = 0, pref_dn = 0;
+  if ((st = hsa_amd_memory_copy_engine_status(s->gpu, s->cpu, &free_up)) != HSA_STATUS_SUCCESS && st != HSA_STATUS_ERROR_OUT_OF_RESOURCES)
+    return fail("hsa_amd_memory_copy_engine_status", st);
+  (void)hsa_amd_memory_copy_engine_status(s->cpu, s->gpu, &free_dn);
+  (void)hsa_amd_memory_get_preferred_copy_engine(s->gpu, s->cpu, &pref_up);
+  (void)hsa_amd_memory_get_preferred_copy_engine(s->cpu, s->gpu, &pref_dn);
+  auto lowest = [](uint32_t m) { return m ? m & (~m + 1u) : 0u; };
+  const uint32_t up = lowest(pref_up & free_up ? pref_up & free_up : free_up);
+  uint32_t dn = lowest((pref_dn & free_dn & ~up) ? (pref_dn & free_dn & ~up) : (free_dn & ~up));
+  if (!up || !dn) return fail("two free copy engines", HSA_STATUS_ERROR_OUT_OF_RESOURCES);
+  s->e_up = (hsa_amd_sdma_engine_id_t)up;
+  s->e_dn = (hsa_amd_sdma_engine_id_t)dn;
+  if (hipMalloc((void **)&s->d_flags, 512) != hipSuccess || hipMemset(s->d_flags, 0, 512) != hipSuccess ||
+      hipHostMalloc((void **)&s->h_seq, Sdma::SEQ * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    return fail("flag memory", HSA_STATUS_ERROR_OUT_OF_RESOURCES);
+  }
+  int can = 0;
+  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, b->device) != hipSuccess || !can) return fail("hipStreamWaitValue64", HSA_STATUS_ERROR);
+  s->ok = true;
+  return s;
+}
+void sdma_free(RNNoiseBatch::HostIo &io) {
+  if (!io.sdma) return;
+  for (hsa_signal_t sg : io.sdma->pool) hsa_signal_destroy(sg);
+  if (io.sdma->d_flags) hipFree(io.sdma->d_flags);
+  if (io.sdma->h_seq) hipHostFree(io.sdma->h_seq);
+  delete io.sdma;
+  io.sdma = nullptr;
+}
+}  // namespace
+
 void host_io_release(RNNoiseBatch *b) {
   RNNoiseBatch::HostIo &io = b->io;
+  sdma_free(io);
   for (int k = 0; k < 2; k++) {
     if (io.d_in[k]) hipFree(io.d_in[k]);
     if (io.h_in[k]) hipHostFree(io.h_in[k]);
@@ -112,9 +211,46 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   // float frames (2 x 126 MB per step) are bound by the link whatever the kernels do, and there both directions at once win:
   // uploads ride on the high-pass stream, downloads keep the copy stream -- 19.9 M frames/s against 14.6 M.
   // $RNNOISE_AMD_HOSTIO_COPY = one | hp forces a mode (A/B runs).
-  static const int copy_mode_env = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY"); return !e ? 0 : (!strcmp(e, "one") ? 1 : 2); }();
-  const bool one_copy_stream = copy_mode_env ? copy_mode_env == 1 : s16;
+  // $RNNOISE_AMD_HOSTIO_COPY = one | hp | sdma forces a mode (A/B runs); sdma: the explicit copy engines above.
+  static const int copy_mode_env = [] {
+    const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY");
+    return !e ? 0 : (!strcmp(e, "one") ? 1 : (!strcmp(e, "sdma") ? 3 : 2));
+  }();
+  const bool one_copy_stream = (copy_mode_env == 1 || copy_mode_env == 2) ? copy_mode_env == 1 : s16;
+  Sdma *sd = (copy_mode_env == 3 || copy_mode_env == 0) ? sdma_get(b, in) : nullptr;
+  // per call: the signals of its frames (reused from call to call: the previous call ended with every copy complete)
+  struct FrameSig { hsa_signal_t hp_read, k3_done, up, up_flag, dn, dn_flag; uint64_t dn_target; };
+  std::vector<FrameSig> fs;
+  hsa_agent_t a_in{}, a_out{}, a_vad{}, a_g{};
+  const void *p_in = nullptr, *p_out = nullptr, *p_vad = nullptr, *p_g = nullptr;
+  if (sd) {
+    sd->used = 0;
+    fs.resize((size_t)n_frames);
+    if (!sdma_owner(in, a_in, p_in) || !sdma_owner(out, a_out, p_out) || (vad && !sdma_owner(vad, a_vad, p_vad)) || (gains && !sdma_owner(gains, a_g, p_g))) sd = nullptr;
+  }
+  auto value_word = [](hsa_signal_t s) { return static_cast<void *>(const_cast<int64_t *>(&reinterpret_cast<amd_signal_t *>(s.handle)->value)); };
+#define HSA_OK(x) do { hsa_status_t s_ = (x); if (s_ != HSA_STATUS_SUCCESS) { const char *m_ = nullptr; hsa_status_string(s_, &m_); \
+    fprintf(stderr, "[rnnoise_amd] %s: %s\n", #x, m_ ? m_ : "?"); return -1; } } while (0)
   hk.before_hp = [&](int f, hipStream_t sc) -> int {
+    if (sd) {
+      FrameSig &q = fs[(size_t)f];
+      q.hp_read = sd->take(1);
+      q.k3_done = sd->take(1);
+      q.up = sd->take(1);
+      q.up_flag = sd->take(1);
+      q.dn = sd->take(1 + (vad ? 1 : 0) + (gains ? 1 : 0));
+      q.dn_flag = sd->take(1);
+      if (!q.dn_flag.handle) return -1;
+      // upload(f) on the upload engine, once high-pass(f - RING) has read the slot; the count of landed uploads behind it
+      const hsa_signal_t *dep = f >= RING ? &fs[(size_t)(f - RING)].hp_read : nullptr;
+      HSA_OK(hsa_amd_memory_async_copy_on_engine(r_in + (size_t)(f % RING) * fsz, sd->gpu, static_cast<const char *>(p_in) + (size_t)f * fsz, a_in, fsz,
+                                                 dep ? 1 : 0, dep, q.up, sd->e_up, false));
+      const uint64_t c = ++sd->up_count;
+      sd->h_seq[c % (Sdma::SEQ / 2)] = c;
+      HSA_OK(hsa_amd_memory_async_copy_on_engine(&sd->d_flags[0], sd->gpu, &sd->h_seq[c % (Sdma::SEQ / 2)], sd->cpu, 8, 1, &q.up, q.up_flag, sd->e_up, false));
+      HIP_OK(hipStreamWaitValue64(sc, &sd->d_flags[0], c, hipStreamWaitValueGte, ~0ull));
+      return 0;
+    }
     if (!one_copy_stream) {
       HIP_OK(hipMemcpyAsync(r_in + (size_t)(f % RING) * fsz, in + (size_t)f * fsz, fsz, hipMemcpyHostToDevice, sc));
       return 0;
@@ -126,10 +262,15 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     return 0;
   };
   hk.after_hp = [&](int f, hipStream_t sc) -> int {
+    if (sd) return rn_launch_release_store(value_word(fs[(size_t)f].hp_read), 0, sc) == hipSuccess ? 0 : -1;
     if (one_copy_stream) HIP_OK(hipEventRecord(io.r_hp[f % RING], sc));
     return 0;
   };
   hk.before_nn = [&](int f, hipStream_t st) -> int {  // network(f) writes vad / gains, synthesis(f) the PCM of slot f % RING
+    if (sd) {
+      if (f >= RING) HIP_OK(hipStreamWaitValue64(st, &sd->d_flags[32], fs[(size_t)(f - RING)].dn_target, hipStreamWaitValueGte, ~0ull));
+      return 0;
+    }
     if (f >= RING) HIP_OK(hipStreamWaitEvent(st, io.r_down[f % RING], 0));
     return 0;
   };
@@ -153,6 +294,22 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
                          !(reinterpret_cast<uintptr_t>(vad_dev) & 15) && !(reinterpret_cast<uintptr_t>(gains_dev) & 15) && N % 4 == 0;
   hk.after_k3 = [&](int f, hipStream_t st) -> int {
     const int k = f % RING;
+    if (sd) {
+      FrameSig &q = fs[(size_t)f];
+      // download(f) on the download engine, released by a store on the kernels' stream; the count of landed downloads behind it
+      HIP_OK(rn_launch_release_store(value_word(q.k3_done), 0, st));
+      HSA_OK(hsa_amd_memory_async_copy_on_engine(const_cast<char *>(static_cast<const char *>(p_out)) + (size_t)f * fsz, a_out, r_out + (size_t)k * fsz, sd->gpu, fsz,
+                                                 1, &q.k3_done, q.dn, sd->e_dn, false));
+      if (vad) HSA_OK(hsa_amd_memory_async_copy_on_engine(const_cast<char *>(static_cast<const char *>(p_vad)) + (size_t)f * N * 4, a_vad, r_vad + (size_t)k * N, sd->gpu,
+                                                          N * sizeof(float), 1, &q.k3_done, q.dn, sd->e_dn, false));
+      if (gains) HSA_OK(hsa_amd_memory_async_copy_on_engine(const_cast<char *>(static_cast<const char *>(p_g)) + (size_t)f * N * RN_NB_BANDS * 4, a_g,
+                                                            r_g + (size_t)k * N * RN_NB_BANDS, sd->gpu, N * RN_NB_BANDS * sizeof(float), 1, &q.k3_done, q.dn, sd->e_dn, false));
+      const uint64_t c = ++sd->dn_count;
+      sd->h_seq[Sdma::SEQ / 2 + c % (Sdma::SEQ / 2)] = c;
+      q.dn_target = c;
+      HSA_OK(hsa_amd_memory_async_copy_on_engine(&sd->d_flags[32], sd->gpu, &sd->h_seq[Sdma::SEQ / 2 + c % (Sdma::SEQ / 2)], sd->cpu, 8, 1, &q.dn, q.dn_flag, sd->e_dn, false));
+      return 0;
+    }
     HIP_OK(hipEventRecord(io.r_k3[k], st));
     HIP_OK(hipStreamWaitEvent(io.down, io.r_k3[k], 0));
     if (by_kernel) {
@@ -179,9 +336,28 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   if (b->schedule == 0) b->schedule = sched_env;
   const int rc = batch_process_device_impl(b, r_out, r_in, r_vad, r_g, n_frames, io.run, s16, &hk);
   b->schedule = keep;
+  if (sd && !rc && n_frames > 0) {
+    // every copy of the call is complete once the last frame's download count has landed (the engines work in order)
+    const hsa_signal_t last = fs[(size_t)n_frames - 1].dn_flag;
+    const uint64_t give_up = 30ull * 1000000000ull;
+    if (hsa_signal_wait_scacquire(last, HSA_SIGNAL_CONDITION_LT, 1, give_up, HSA_WAIT_STATE_BLOCKED) >= 1) {
+      fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: the copy engines did not finish within 30 s\n");
+      (void)hipDeviceSynchronize();
+      (void)rnnoise_batch_reset(b);
+      return -1;
+    }
+  }
   if (rc) {
     // whatever was queued must not outlive the caller's buffers; and some of the call's frames may have run while the batch's
     // frame bookkeeping was not advanced: the streams are no longer in a state any caller knows -- back to the initial one
+    if (sd) {  // (copies parked on signals that no kernel will release any more: release them by hand, then drain)
+      for (FrameSig &q : fs) {
+        if (q.hp_read.handle) hsa_signal_store_screlease(q.hp_read, 0);
+        if (q.k3_done.handle) hsa_signal_store_screlease(q.k3_done, 0);
+      }
+      for (FrameSig &q : fs)
+        if (q.dn_flag.handle && q.dn_target) (void)hsa_signal_wait_scacquire(q.dn_flag, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+    }
     (void)hipDeviceSynchronize();
     fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: a GPU step failed inside the call; the batch has been reset\n");
     (void)rnnoise_batch_reset(b);
@@ -190,6 +366,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   HIP_OK(hipStreamSynchronize(io.down));
   HIP_OK(hipStreamSynchronize(io.run));  // (the side streams of the pipelined schedule join `run` before its last kernel)
   return 0;
+#undef HSA_OK
 }
 
 static int batch_process_host_impl(RNNoiseBatch *b, void *out_v, const void *in_v, float *vad, float *gains, int n_frames,

@@ -46,6 +46,7 @@ extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, 
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
+extern "C" hipError_t rn_launch_release_store(void *, long long, hipStream_t);
 #if RN_INSTRUMENT
 extern "C" hipError_t rn_launch_log_energy(const float *, unsigned, float *, unsigned, const double *, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
@@ -185,6 +186,7 @@ struct RNNoiseBatch {
     static constexpr int RING = 6;
     char *ring_mem = nullptr;
     hipEvent_t r_k3[RING] = {}, r_down[RING] = {}, r_up[RING] = {}, r_hp[RING] = {};
+    struct Sdma *sdma = nullptr;  // copy mode "sdma" (host_io.cpp): explicit copy engines underneath HIP, created on first use
   } io;
   // timing
   bool timing = false;

@@ -104,3 +104,14 @@ extern "C" hipError_t rn_launch_copy_to_host(void *dst, const void *src, size_t 
                      reinterpret_cast<const uint32_t *>(static_cast<const char *>(src) + 16 * n16), n_tail);
   return hipGetLastError();
 }
+
+// One 64-bit store with system-scope release: how a HIP stream releases an explicit SDMA-engine copy that lists an HSA signal as its
+// dependency (host_io.cpp, copy mode "sdma": p = the value word of the signal; everything the stream's earlier kernels wrote is
+// visible to the copy engine that sees the 0).
+extern "C" __global__ void rn_release_store_kernel(long long *p, long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" hipError_t rn_launch_release_store(void *p, long long v, hipStream_t st) {
+  hipLaunchKernelGGL(rn_release_store_kernel, dim3(1), dim3(1), 0, st, static_cast<long long *>(p), v);
+  return hipGetLastError();
+}
