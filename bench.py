@@ -152,7 +152,7 @@ def step_valu_issue_ms(n_streams: int, model: str = "default", nn: str = "mfma")
     if nn != "mfma":
         return None
     if n >= NN_LAYERS_MIN_STREAMS:
-        launches += [("rn_nn_front_kernel", -(-n // 16) * 8), ("rn_nn_gru_kernel", 3 * (-(-n // 64)) * 8), ("rn_nn_dense_kernel", -(-n // 64) * 8)]
+        launches += [("rn_nn_front_kernel", -(-n // 16) * 8), ("rn_nn_gru_kernel", 3 * (-(-n // 64)) * 4), ("rn_nn_dense_kernel", -(-n // 64) * 8)]
     else:
         launches += [("rn_nn_mfma_kernel", -(-n // 16) * 8)]
     cycles = 0.0  # (seconds x SIMDs: every kernel at the clock it was measured at)
@@ -655,6 +655,17 @@ def bench_rank(a) -> dict | None:
                                                             "profiles/r4_valu_issue.txt), over 1024 SIMDs at each kernel's measured clock, divided by ms_per_step"}
         except Exception:
             pass
+        if not stub and a.nn == "mfma":
+            # north_star's condition on the MFMA path ("rocprof shows real MFMA utilisation"): SQ_VALU_MFMA_BUSY_CYCLES of each network
+            # kernel over (1,024 SIMDs x the launch's GPU-active cycles), from the PMC passes kept under profiles/
+            mf = {}
+            for kn in sorted(set(NN_LAYER_KERNELS if N >= NN_LAYERS_MIN_STREAMS else ("rn_nn_mfma_kernel",))):
+                rec = pmc_record(kn, N, a.model) or {}
+                if "mfma_busy_frac" in rec:
+                    mf[kn] = {"busy_frac": rec["mfma_busy_frac"], "mfma_per_wave": rec.get("mfma_per_wave"), "source": rec.get("source")}
+            if mf:
+                line["mfma_utilisation"] = {"definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per launch, one-stream schedule",
+                                            "kernels": mf}
         if stub:
             line["stub"] = True
         if share and world > 1:

@@ -279,9 +279,13 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
   const int pipe_force = b->schedule ? b->schedule : pipe_env;
   const bool pipelined = n_frames > 1 && pipe_force != 9;
   const bool side_k1 = pipelined && pipe_force != 1;
-  if (side_k1 && !b->side) HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  // $RNNOISE_AMD_SIDE_PRIO = <k1>,<hp> (A/B runs): queue priorities of the two side streams, -1 high / 0 normal / 1 low (the caller's
+  // stream, which carries network + synthesis, is whatever the caller made it: normal for torch's)
+  static const int side_prio[2] = {[] { const char *e = getenv("RNNOISE_AMD_SIDE_PRIO"); return e ? atoi(e) : 0; }(),
+                                   [] { const char *e = getenv("RNNOISE_AMD_SIDE_PRIO"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }()};
+  if (side_k1 && !b->side) HIP_OK(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, side_prio[0]));
   if (pipelined && !b->side_hp) {
-    HIP_OK(hipStreamCreateWithFlags(&b->side_hp, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithPriority(&b->side_hp, hipStreamNonBlocking, side_prio[1]));
     // ordering between streams of ONE device: no system-scope fence (it writes back and invalidates the caches at
     // every record, which the next kernels then pay for)
     // ($RNNOISE_AMD_EVENT_FENCE=1, A/B runs only: ordering events with the system-scope fence back on)

@@ -1164,13 +1164,15 @@ GRU3_KERNEL(rn_nn_gru3_neither_kernel, GRU_PERSIST | GRU_BD | GRU3_NOACT | GRU3_
 GRU3_KERNEL(rn_nn_gru3_hita_kernel, GRU_PERSIST | GRU_BD | GRU3_HITA)
 GRU3_KERNEL(rn_nn_gru3_hita_neither_kernel, GRU_PERSIST | GRU_BD | GRU3_HITA | GRU3_NOACT | GRU3_NOMFMA)
 
-extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  gru_body<2, 8, 3, false>(g, m, tb, layer);
+// The shipping form since round 5: four waves, one row buffer per wave, 72 KB -- two workgroups per CU (round 4 shipped the eight-wave
+// 152 KB form below; profiles/r5_gru_bound.txt has the A/B and profiles/r5_gru_race.txt why this one could not ship before)
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+rn_nn_gru_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 4, 1, false>(g, m, tb, layer);
 }
 // A/B variants (not taken by default): see GruLdsT
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-rn_nn_gru_w4_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
-  gru_body<2, 4, 1, false>(g, m, tb, layer);
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_w8_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 3, false>(g, m, tb, layer);
 }
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 rn_nn_gru_w4b2_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
@@ -1212,10 +1214,10 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
   typedef void (*Kernel)(RnGroupDev, RnModelDev, RnTablesDev, int);
   struct Variant { const char *name; Kernel k; int threads; size_t lds; bool persist; };
   static const Variant variants[] = {
-      {"w8", rn_nn_gru_kernel, 512, sizeof(GruLdsT<8, 3>), false},          {"w4", rn_nn_gru_w4_kernel, 256, sizeof(GruLdsT<4, 1>), false},
+      {"w4", rn_nn_gru_kernel, 256, sizeof(GruLdsT<4, 1>), false},          {"w8", rn_nn_gru_w8_kernel, 512, sizeof(GruLdsT<8, 3>), false},
       {"w4b2", rn_nn_gru_w4b2_kernel, 256, sizeof(GruLdsT<4, 2>), false},   {"w8b1", rn_nn_gru_w8b1_kernel, 512, sizeof(GruLdsT<8, 1>), false},
       {"w4nodma", rn_nn_gru_w4nodma_kernel, 256, sizeof(GruLdsT<4, 1>), false},  // no LDS-DMA: pieces through registers
-      {"w4big", rn_nn_gru_w4_kernel, 256, sizeof(GruLdsT<8, 3>), false},  // the w4 kernel asking for a whole CU's LDS: one workgroup per CU
+      {"w4big", rn_nn_gru_kernel, 256, sizeof(GruLdsT<8, 3>), false},  // the w4 kernel asking for a whole CU's LDS: one workgroup per CU
       // round 5 (gru_body2): o0 = the restructured body with nothing switched on, then one change at a time, then together
       {"o0", rn_nn_gru2_o0_kernel, 512, sizeof(GruLds2T<1>), false},        {"bd", rn_nn_gru2_bd_kernel, 512, sizeof(GruLds2T<1>), false},
       {"deep", rn_nn_gru2_deep_kernel, 512, sizeof(GruLds2T<1>), false},    {"ax", rn_nn_gru2_ax_kernel, 512, sizeof(GruLds2T<1>), false},

@@ -21,16 +21,17 @@ python "$R/bench.py" --no-cpu-baseline --streams 4096 --steps 50 --warmup 10 --f
 python "$R/bench.py" --no-cpu-baseline --streams 16384 --steps 40 --warmup 8 --frames-per-call 1 > "$O/b.log" 2>&1;  last "$O/b.log" > "$O/bench_16384_fpc1.json"
 python "$R/tools/pcie_peak.py" 2>&1 | grep pinned > "$O/pcie_peak.txt"
 python "$R/tools/serial_times.py" 1 64 1024 4096 16384 65536 2>&1 | grep "N=" > "$O/serial_times.txt"
-timeout 600 "$R/rnnoise_amd/csrc/build/valu_issue" > "$O/valu_issue.txt" 2>&1
+# (the VALU issue table does not depend on the library: COLLECT_VALU_ISSUE=1 re-measures it, otherwise the last round's stays)
+[ "${COLLECT_VALU_ISSUE:-0}" = 1 ] && timeout 600 "$R/rnnoise_amd/csrc/build/valu_issue" > "$O/valu_issue.txt" 2>&1
 RNNOISE_AMD_NN_LAYERS_MIN=100000000 python "$R/tools/ab_layers.py" 65536 2>&1 | grep -E "^N=|^n=" > "$O/network_schedules_65536.txt"
 python "$R/tools/k1_cycles.py" 65536 --nn --layers 2>&1 | grep -v amdgpu.ids > "$O/section_taps_65536.txt"
 python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"
-# the drop-in call from plain C threads (the combiner of dropin.cpp), and the same with a stream per state as in round 3
-( cd "$R" && gcc -O2 -Iinclude tools/configs0_mt.c -o /tmp/configs0_mt -Lrnnoise_amd -l:librnnoise_amd.so -Wl,-rpath,$R/rnnoise_amd -lpthread )
-python -c "import lzma;open('/tmp/default.blob','wb').write(lzma.decompress(open('$R/tests/golden/default.blob.xz','rb').read()))"
-: > "$O/configs0_cthreads.txt"
-for t in 1 2 4 8 16 32 64; do timeout 120 /tmp/configs0_mt /tmp/default.blob $t 3000 2>&1 | sed "s/^/combined launches:   /" >> "$O/configs0_cthreads.txt"; done
-for t in 1 4 16 64; do RNNOISE_AMD_COMBINE=0 timeout 200 /tmp/configs0_mt /tmp/default.blob $t 2000 2>&1 | sed "s/^/a stream per state:  /" >> "$O/configs0_cthreads.txt"; done
+# the drop-in call from plain C threads (the combiner of dropin.cpp): throughput, CPU time per frame, more states than threads, pool sizes
+bash "$R/tools/configs0_scope.sh" 2>&1 | grep -v amdgpu.ids > "$O/configs0_cthreads.txt"
+# round 5: the host-fed path's copy modes, the layer kernel's variants, what the frame pipeline hides
+bash "$R/tools/hostio_sdma.sh" 2>&1 | grep -v amdgpu.ids > "$O/hostio_sdma.txt"
+python "$R/tools/gru_variants.py" w4 w8 p v3 2>&1 | grep -v amdgpu.ids > "$O/gru_variants.txt"
+python "$R/tools/overlap_table.py" 2>&1 | grep -v amdgpu.ids > "$O/overlap.txt"
 python "$R/tools/fft_bench.py" 2>&1 | grep -v amdgpu.ids > "$O/fft_bench.txt"
 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline --repeats 5 > "$O/trace.log" 2>&1
 python "$R/tools/prof_summary.py" "$(ls "$O"/trace/*/*_results.db | head -1)" \

@@ -17,19 +17,19 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 # "round-4 K0" = the high-pass kernel as it shipped until round 4, built WITH the SLP vectoriser (hp_slp.hip: packed multiplies with
 # op_sel operand selects); it only exists in the instrumented library ($RNNOISE_AMD_HP_AB=2048).  The product's K0 has no packed math.
 OLD_K0 = {"RNNOISE_AMD_HP_AB": "2048"}
-W4, HPSIDE = {"RNNOISE_AMD_GRU_VARIANT": "w4"}, {"RNNOISE_AMD_PIPE": "1"}
+W4, W8, HPSIDE = {"RNNOISE_AMD_GRU_VARIANT": "w4"}, {"RNNOISE_AMD_GRU_VARIANT": "w8"}, {"RNNOISE_AMD_PIPE": "1"}
 CONFIGS = {
     # the product library
-    "product: w8 layer kernel (shipping), three-stream pipeline": ({}, False),
-    "product: w8, only the high-pass on a side stream (the host-fed path's schedule)": (HPSIDE, False),
-    "product: w4 layer kernel (4 waves, 72 KB: shares SIMDs with other kernels' waves), three-stream pipeline": (W4, False),
+    "product: w8 layer kernel (8 waves, 152 KB: what shipped until round 4), three-stream pipeline": (W8, False),
+    "product: w8, only the high-pass on a side stream (the host-fed path's schedule)": ({**W8, **HPSIDE}, False),
+    "product: w4 layer kernel (4 waves, 72 KB: shares SIMDs with other kernels' waves; the default since round 5), three-stream pipeline": (W4, False),
     "product: w4, only the high-pass on a side stream": ({**W4, **HPSIDE}, False),
     "product: w4b2 (4 waves, two row buffers), only the high-pass on a side stream": ({"RNNOISE_AMD_GRU_VARIANT": "w4b2", **HPSIDE}, False),
     # the failure of round 4, reproduced: the same library with the round-4 K0
     "round-4 K0 + w4, three-stream pipeline (round 4's unstable configuration)": ({**W4, **OLD_K0}, True),
     "round-4 K0 + w4, only the high-pass on a side stream": ({**W4, **HPSIDE, **OLD_K0}, True),
     "round-4 K0 + w4, everything on one stream (K0 never beside the layer kernel)": ({**W4, "RNNOISE_AMD_PIPE": "9", **OLD_K0}, True),
-    "round-4 K0 + w8, only the high-pass on a side stream (a w8 workgroup leaves no registers for a K0 wave on its SIMDs)": ({**HPSIDE, **OLD_K0}, True),
+    "round-4 K0 + w8, only the high-pass on a side stream (a w8 workgroup leaves no registers for a K0 wave on its SIMDs)": ({**W8, **HPSIDE, **OLD_K0}, True),
     # what it is not
     "round-4 K0 + w4 hp-side, a workgroup barrier between the layer kernel's vmcnt(0) and its row reads": ({**W4, **HPSIDE, **OLD_K0, "RNNOISE_AMD_GRU_SETTLE": "2"}, True),
     "round-4 K0 + w4 hp-side, ordering events WITH the system-scope fence": ({**W4, **HPSIDE, **OLD_K0, "RNNOISE_AMD_EVENT_FENCE": "1"}, True),
@@ -40,7 +40,7 @@ CONFIGS = {
     "round-4 K0 + w4 hp-side, K0 drains its tap stores before it ends": ({**W4, **HPSIDE, "RNNOISE_AMD_HP_AB": str(2048 + 1024)}, True),
     # the layer kernel's own inputs, checked word by word against HBM while the failure happens
     "round-4 K0 + w4chk hp-side (every LDS row / image word the layer kernel uses compared with HBM)": ({"RNNOISE_AMD_GRU_VARIANT": "w4chk", **HPSIDE, **OLD_K0}, True),
-    "w8chk, three-stream pipeline (the shipping kernel's rows and images compared with HBM)": ({"RNNOISE_AMD_GRU_VARIANT": "w8chk"}, True),
+    "w8chk, three-stream pipeline (the eight-wave kernel's rows and images compared with HBM)": ({"RNNOISE_AMD_GRU_VARIANT": "w8chk"}, True),
 }
 FIELDS = (("analysis_mem", 0, 480), ("synthesis_mem", 480, 480), ("pitch_buf", 960, 1728), ("last_gain", 2688, 1), ("last_period", 2689, 1),
           ("mem_hp", 2690, 2), ("lastg", 2692, 32), ("conv1_state (the last two frames' features)", 2724, 130), ("conv2_state", 2854, 256),

@@ -21,7 +21,7 @@ for n in ("k1_sections.csv",):
     if os.path.exists(os.path.join(src, n)):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{pre}_{n}"))
 for n in ("serial_times", "section_taps_65536", "configs0", "configs0_cthreads", "k1_sections", "k1_narrow", "fft_bench", "network_schedules_65536", "pcie_peak",
-          "valu_issue"):
+          "valu_issue", "hostio_sdma", "gru_variants", "overlap"):
     if os.path.exists(os.path.join(src, n + ".txt")):
         shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
@@ -51,9 +51,11 @@ for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warm
            "# (MFMA path, every kernel on one stream so that a kernel's counters are its own); one run per counter group (tools/pmc_collect.py);\n"
            "# SQ_* are summed over all shader engines, *_CYCLES in quad-cycles; cyc/VALU = 4*SQ_ACTIVE_INST_VALU/SQ_INSTS_VALU;\n"
            "# clock = GRBM_GUI_ACTIVE / XCDs / duration of the same pass (GHz); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is in KiB\n"
-           "# and on gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section)\n")
+           "# and on gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section);\n"
+           "# MFMA_busy% = SQ_VALU_MFMA_BUSY_CYCLES (cycles: 16 per v_mfma_i32_16x16x64_i8, 32 per v_mfma_f32_16x16x4_f32) / (1,024 SIMDs x the kernel's\n"
+           "# GRBM_GUI_ACTIVE / 8 XCDs): the share of the launch during which a SIMD's matrix pipe is busy, averaged over the SIMDs\n")
     t = (f"{'kernel':<26}{'waves':>8}{'VALU/wave':>10}{'SALU/wave':>10}{'LDS/wave':>9}{'MFMA/wave':>10}{'VMEM/wave':>10}{'cyc/VALU':>9}"
-         f"{'valu_act%':>10}{'wait%':>7}{'LDScyc/wave':>12}{'conflict%':>10}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}{'clock_GHz':>10}\n")
+         f"{'valu_act%':>10}{'wait%':>7}{'LDScyc/wave':>12}{'conflict%':>10}{'L2hit%':>8}{'FETCH_KiB':>11}{'WRITE_KiB':>11}{'HBM_B/frame':>12}{'clock_GHz':>10}{'MFMA_busy%':>11}\n")
     for r in rows:
         def g(k):
             return float(r[k]) if r.get(k) else 0.0
@@ -68,7 +70,9 @@ for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warm
               f"{g('FETCH_SIZE'):>11.0f}{g('WRITE_SIZE'):>11.0f}{hbm:>12.0f}")
         cl = next((g("GRBM_GUI_ACTIVE") / dv / g("GRBM_PASS_DURATION_NS") for dv in (1, 8)
                    if g("GRBM_PASS_DURATION_NS") and 0.5 <= g("GRBM_GUI_ACTIVE") / dv / g("GRBM_PASS_DURATION_NS") <= 3.0), 0.0)
-        t += f"{cl:>10.3f}\n" if cl else f"{'':>10}\n"
+        t += f"{cl:>10.3f}" if cl else f"{'':>10}"
+        busy = 100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * g("GRBM_GUI_ACTIVE") / 8) if g("GRBM_GUI_ACTIVE") else 0.0
+        t += f"{busy:>11.1f}\n" if g("SQ_INSTS_MFMA") else f"{'':>11}\n"
         # shader clock of the kernel: GRBM_GUI_ACTIVE (busy cycles, summed over the XCDs rocprofv3 reports) / its duration in
         # the same pass; the divisor (1 or 8 XCDs) is the one that lands in a shader clock's range
         clock = None
@@ -82,7 +86,8 @@ for tag, model, n_streams, cmd in (("65536", "default", 65536, "--steps 4 --warm
             **({"clock_ghz": clock} if clock else {}),
             "hbm_bytes_per_frame": round(hbm, 1), "fetch_kib_per_launch": g("FETCH_SIZE"), "write_kib_per_launch": g("WRITE_SIZE"),
             "valu_per_wave": round(g("SQ_INSTS_VALU") / w), "valu_cycles_per_inst": round(cpi, 2),
-            "lds_cycles_per_wave": round(g("SQ_LDS_IDX_ACTIVE") / w), "kernel": r["kernel"], "source": f"profiles/{pre}_pmc_{tag}.txt"}
+            "lds_cycles_per_wave": round(g("SQ_LDS_IDX_ACTIVE") / w), "kernel": r["kernel"], "source": f"profiles/{pre}_pmc_{tag}.txt",
+            **({"mfma_per_wave": round(g("SQ_INSTS_MFMA") / w), "mfma_busy_frac": round(busy / 100, 4)} if g("SQ_INSTS_MFMA") else {})}
     open(os.path.join(dst, f"{pre}_pmc_{tag}.txt"), "w").write(hdr + t)
     print(hdr + t)
 json.dump({"source": f"profiles/{pre}_pmc_*.txt (rocprofv3 --pmc, separate passes, gfx950 x2 read correction); bench.py uses the set of its "
