@@ -262,6 +262,7 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
   const int N = g.n_streams, n_tiles = (N + TS - 1) / TS, tile0 = blockIdx.x * GM;
   const uint16_t *lut = L.lut;
+  if (lds_addr(L.lut) != 0) __builtin_trap();  // (the *_lut0 activations take the table index for its LDS address)
   float *st = g.gru_state + (size_t)layer * g.n_stride * RN_GRU;
   const int8_t *xin = g.act_q[layer];
   int8_t *himg = g.act_q[layer + 1];  // quantised state: read here, rewritten below (own tiles only)
@@ -468,22 +469,24 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
         for (int p = 0; p < 2; p++) {
           const v2f gz = {gi[0][t][2 * p], gi[0][t][2 * p + 1]}, rz = {gr[0][t][2 * p], gr[0][t][2 * p + 1]};
           const v2f gg = {gi[1][t][2 * p], gi[1][t][2 * p + 1]}, rr = {gr[1][t][2 * p], gr[1][t][2 * p + 1]};
-          az[p] = sigmoid_pre2(gz + rz, lut);
-          ar[p] = sigmoid_pre2(gg + rr, lut);
+          // (the *_lut0 / *_k forms: the table index is the LDS address -- the table is this kernel's first LDS member, checked at
+          //  the top -- and the reciprocal is rebuilt in two operations: 2 VALU instructions fewer per activation, the same integers)
+          az[p] = sigmoid_pre2_lut0(gz + rz);
+          ar[p] = sigmoid_pre2_lut0(gg + rr);
         }
         __builtin_amdgcn_sched_barrier(0);
         v2f z[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-          z[p] = sigmoid_fin2(az[p]);
+          z[p] = sigmoid_fin2_k(az[p]);
           const v2f gh = {gi[2][t][2 * p], gi[2][t][2 * p + 1]}, rh = {gr[2][t][2 * p], gr[2][t][2 * p + 1]};
-          ah[p] = tanh_pre2(gh + rh * sigmoid_fin2(ar[p]), lut);
+          ah[p] = tanh_pre2_lut0(gh + rh * sigmoid_fin2_k(ar[p]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 2; p++) {
           const v2f ho = {h_old[t][2 * p], h_old[t][2 * p + 1]};
-          const v2f hv = z[p] * ho + (v2f{1.f, 1.f} - z[p]) * tanh_fin2(ah[p]);
+          const v2f hv = z[p] * ho + (v2f{1.f, 1.f} - z[p]) * tanh_fin2_k(ah[p]);
           hn[2 * p] = hv.x;
           hn[2 * p + 1] = hv.y;
         }
