@@ -86,7 +86,10 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
     if kind == "network":
         if nn != "mfma":
             return "rn_nn_one_kernel" if n_streams <= NN_ONE_MAX_STREAMS else "rn_nn_vector_kernel"
-        return "rn_nn_gru_kernel" if n_streams >= NN_LAYERS_MIN_STREAMS else "rn_nn_mfma_kernel"
+        if n_streams < NN_LAYERS_MIN_STREAMS:
+            return "rn_nn_mfma_kernel"
+        # (nn_layers.hip: the four-wave form once there are more 64-stream groups than CUs, the eight-wave one below)
+        return "rn_nn_gru_kernel" if -(-n_streams // 64) > N_CU else "rn_nn_gru_w8_kernel"
     if kind == "analysis" and k1_single(n_streams):
         return "rn_analysis_single_kernel"  # one stream per workgroup
     if kind == "highpass" and n_streams <= HP_ONE_MAX_STREAMS:
@@ -203,7 +206,7 @@ def pmc_record(kernel: str, n_streams: int, model: str = "default"):
             allsets = json.load(f)
         sets = allsets.get(model) if model != "default" and allsets.get(model) else allsets["by_streams"]
         k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]
-        return k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", ""))
+        return k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", "").replace("_w8", ""))
     except Exception:
         return None
 

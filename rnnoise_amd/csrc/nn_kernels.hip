@@ -380,8 +380,15 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
   // buffer was last read by chain k - 1, one barrier ago).  (One wave issuing all 48 pieces after its chain spent 7 k cycles
   // in the issue alone -- the memory pipeline takes a 1 KB piece every ~150 cycles from one wave -- and everybody waited for it
   // at the layer's barrier.)
+  // (lane-number derivatives that are needed once per layer, or once at the end, are re-derived from the thread id through an opaque
+  //  copy where they are used: kept in registers from the top they pushed the kernel 5 registers over the 128 its 14 waves allow)
+  auto late_lane = [&] {
+    int v = (int)threadIdx.x;
+    asm volatile("" : "+v"(v));
+    return v & 63;
+  };
   auto fetch_pieces = [&](int seg, int first, int count) {
-    const char *src = reinterpret_cast<const char *>(m.dense_out.fw4) + (size_t)seg * 49152 + lane * 16;
+    const char *src = reinterpret_cast<const char *>(m.dense_out.fw4) + (size_t)seg * 49152 + late_lane() * 16;
     const unsigned dst = one_lds_addr(O.big) + (seg & 1) * 49152;
     for (int i = first; i < first + count; i++) one_dma_1k(src + i * 1024, dst + i * 1024);
   };
@@ -470,8 +477,12 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
     if (!chain_wave && !half) L.cat[(k + 1) * RN_GRU + u] = h_old;
     __syncthreads();  // segment k of cat is final (conv2 output / the previous layer's new state)
     if (k == 0) ONE_TAP();  // 3: layer 0: barrier
-    if (t < 96) L.xq[t] = pack4(L.cat + k * RN_GRU + 4 * t);
-    else if (t >= 128 && t < 224) L.hq[t - 128] = pack4(L.cat + (k + 1) * RN_GRU + 4 * (t - 128));
+    {  // (the thread id through an opaque copy: see late_lane)
+      int tp = (int)threadIdx.x;
+      asm volatile("" : "+v"(tp));
+      if (tp < 96) L.xq[tp] = pack4(L.cat + k * RN_GRU + 4 * tp);
+      else if (tp >= 128 && tp < 224) L.hq[tp - 128] = pack4(L.cat + (k + 1) * RN_GRU + 4 * (tp - 128));
+    }
     __syncthreads();
     if (k == 0) ONE_TAP();  // 4: layer 0: quantised inputs packed, barrier
 #if RN_INSTRUMENT
@@ -519,8 +530,9 @@ rn_nn_one_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, RnRows rows) {
   if (chain_wave) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     chain_segment(3);
-    if (!vad_wave && lane < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + ct] = sigmoid_x86(cacc + m.dense_out.bias[ct], lut);
-    else if (vad_wave && lane == 0) *vad_dst = sigmoid_x86(cacc + m.vad_dense.bias[0], lut);
+    const int ll = late_lane(), lct = ll & 31;
+    if (!vad_wave && ll < RN_NB_BANDS) g.gains[(size_t)s * RN_NB_BANDS + lct] = sigmoid_x86(cacc + m.dense_out.bias[lct], lut);
+    else if (vad_wave && ll == 0) *vad_dst = sigmoid_x86(cacc + m.vad_dense.bias[0], lut);
   }
   ONE_TAP();  // 6: last chain segment + outputs
 #undef ONE_TAP

@@ -1240,27 +1240,32 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
 #endif
   };
   constexpr int NV = sizeof(variants) / sizeof(variants[0]);
-  // $RNNOISE_AMD_GRU_VARIANT (A/B runs; an unknown name is an error, not a silent default)
-  static const int vi = [] {
+  // $RNNOISE_AMD_GRU_VARIANT (A/B runs; an unknown name is an error, not a silent default).  Unset: by batch size --
+  // the four-wave form (two workgroups per CU: 1-3 % under the eight-wave one stand-alone in every A/B of profiles/r5_gru_bound.txt)
+  // once there are more groups than CUs; the eight-wave form while every group has a CU to itself (a four-wave workgroup would then
+  // leave each SIMD with ONE wave: 16,384 streams 0.200 against 0.174 ms for the three layers + front + dense)
+  static const int vi_env = [] {
     const char *e = getenv("RNNOISE_AMD_GRU_VARIANT");
-    if (!e || !*e) e = "w4";  // round 5: four waves, 72 KB -- two workgroups per CU (1-3 % under "w8" stand-alone in every A/B of profiles/r5_gru_bound.txt)
+    if (!e || !*e) return -2;
     for (int i = 0; i < NV; i++)
       if (!strcmp(e, variants[i].name)) return i;
     fprintf(stderr, "[rnnoise_amd] RNNOISE_AMD_GRU_VARIANT=%s: no such variant in this build\n", e);
     return -1;
   }();
-  if (vi < 0) return hipErrorInvalidValue;
-  const Variant &v = variants[vi];
-  // more than 64 KB of LDS is an opt-in, per device (a process may hold batches on several GPUs)
-  static bool opted[64] = {};
+  if (vi_env == -1) return hipErrorInvalidValue;
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (!opted[dev]) {
+  if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)) cus[dev] = 256;
+  const int n_groups_ = (n_tiles + GM - 1) / GM;
+  const int vi = vi_env >= 0 ? vi_env : (n_groups_ > cus[dev] ? 0 : 1);  // variants[0] = w4, [1] = w8
+  const Variant &v = variants[vi];
+  // more than 64 KB of LDS is an opt-in, per kernel and device (a process may hold batches on several GPUs)
+  static bool opted[NV][64] = {};
+  if (!opted[vi][dev]) {
     const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
     if (attr != hipSuccess) return attr;
-    if (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0) cus[dev] = 256;
-    opted[dev] = true;
+    opted[vi][dev] = true;
   }
   // persistent variants: one workgroup per CU, each walking over groups b, b + grid, ... -- $RNNOISE_AMD_GRU_GRID overrides the count (A/B)
   static const int grid_env = [] {

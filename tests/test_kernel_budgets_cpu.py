@@ -63,7 +63,8 @@ def test_register_budgets(built):
     assert gru["rn_nn_gru_kernel"]["vgpr_count"] <= 256 and gru["rn_nn_gru_kernel"]["vgpr_spill_count"] == 0  # two waves per SIMD
     assert gru["rn_nn_dense_kernel"]["vgpr_count"] <= 128
     one, _ = built["nn_kernels"]
-    assert one["rn_nn_one_kernel"]["vgpr_spill_count"] <= 5  # (known: its 14-wave workgroup caps it at 128 VGPRs)
+    # (its 14-wave workgroup caps it at 128 VGPRs; round 5: 5 -> 1 spilled dword, a quad's LDS address that is reloaded once per layer)
+    assert one["rn_nn_one_kernel"]["vgpr_spill_count"] <= 1
 
 
 def test_no_flat_or_scratch_memory_instructions_in_the_hot_kernels(built):
