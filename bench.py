@@ -463,7 +463,10 @@ def bench_rank(a) -> dict | None:
     def barrier():
         sync()
         if dist:
-            dist.barrier(group=data_group)
+            if collective == "rccl":
+                dist.barrier(group=data_group, device_ids=[gpu_index])  # (explicit: no guessing of the rank's device)
+            else:
+                dist.barrier(group=data_group)
         sync()
 
     # weak scaling: `streams` per GPU; this rank's global stream ids seed its signals
