@@ -171,11 +171,17 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
 // the other in a lane, the 2x decimation is spread over the wave, and global memory is touched in coalesced rows only
 // (frame and pitch_buf come in through LDS).  43 us -> 22 us for one stream (the biquad chain alone is ~8 us).
 // ---------------------------------------------------------------------------------------------
+// One array, used three times over (round 5: 12.5 -> 6.9 KB per wave, so that 16 waves fit a CU and a 4,096-stream batch is ONE round):
+//   pb[0 .. 1727]     pitch_buf of this frame: 1248 old samples from the ring, then the 480 new ones --
+//   pb[1248 .. 1727]  first the UNFILTERED frame: the biquad runs in place (a block's samples are in registers, and the next block's
+//                     too, before its outputs are stored);
+//   pb[0 .. 935]      finally the decimated signal (+ zeros for the reads of the idle lanes of the lag chains): the 2x decimation runs
+//                     in place as well -- pass i reads samples 128 i - 1 .. 128 i + 127 and then writes 64 i .. 64 i + 63, which no
+//                     later pass reads.
 struct HpOneLds {
-  float pb[RN_PITCH_BUF_SIZE];  // pitch_buf of this frame: 1248 old samples from the ring, then the 480 just filtered
-  float xin[RN_FRAME_SIZE];
-  float xlp[864 + 64 + 8];      // decimated signal (+ room for the reads of the idle lanes of the lag chains)
+  float pb[RN_PITCH_BUF_SIZE];
 };
+static_assert(864 + 64 + 8 <= RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, "the decimated signal and its pad stay below the new frame");
 
 extern "C" __global__ void __launch_bounds__(WAVE)
 rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
@@ -213,7 +219,7 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
-      if (lane + 64 * i < RN_FRAME_SIZE / 4) reinterpret_cast<float4 *>(L.xin)[lane + 64 * i] = f[i];
+      if (lane + 64 * i < RN_FRAME_SIZE / 4) reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE))[lane + 64 * i] = f[i];
 #pragma unroll
     for (int i = 0; i < 5; i++)
       if (lane + 64 * i < (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
@@ -221,8 +227,8 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
   __syncthreads();
   // rnn_biquad (src/denoise.c:409-419), once per wave: every lane reads the same samples and computes the same states
   {
-    const float4 *xi4 = reinterpret_cast<const float4 *>(L.xin);
     float4 *yo4 = reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE));
+    const float4 *xi4 = yo4;  // (in place)
     constexpr int BLK = 8;
     float4 cur[BLK], nxt[BLK];
 #pragma unroll
@@ -267,23 +273,26 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
     // transform of X (rn_analysis_rows_kernel): the lags, a third of this kernel's time, are not formed here (bit 8 of
     // slot_arg set by the launcher: they ARE wanted -- the one-wave analysis of $RNNOISE_AMD_ROWS_K1=1)
     if (listed && !(slot_arg & 256)) return;
+    float *xlp = L.pb;  // (in place: see HpOneLds)
 #pragma unroll
     for (int i = 0; i < 14; i++) {
       const int t = lane + 64 * i;
       if (t < 864) {
-        const float c = L.pb[2 * t], r = L.pb[2 * t + 1];
-        L.xlp[t] = (t == 0) ? .5f * (.5f * r + c) : .5f * (.5f * (L.pb[2 * t - 1] + r) + c);
+        const float c = L.pb[2 * t], r = L.pb[2 * t + 1], l = L.pb[t ? 2 * t - 1 : 0];
+        __builtin_amdgcn_sched_barrier(0);  // (this pass's reads, every lane's, before its writes)
+        xlp[t] = (t == 0) ? .5f * (.5f * r + c) : .5f * (.5f * (l + r) + c);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (lane < 8) L.xlp[864 + lane] = 0;
-    L.xlp[872 + lane] = 0;
+    if (lane < 8) xlp[864 + lane] = 0;
+    xlp[872 + lane] = 0;
   }
   __syncthreads();
   // 5-lag autocorrelation (src/celt_lpc.c:92-174): lane k = lag k, terms in the reference's order; terms i >= 860 form the
   // tail chain d (rnn_pitch_xcorr runs over fastN = 860 terms, the rest is added afterwards)
   float acl = 0, dl = 0;
   {
-    const float *xa = L.xlp, *xb = L.xlp + lane;
+    const float *xa = L.pb, *xb = L.pb + lane;
 #pragma unroll 20
     for (int i = 0; i < 860; i++) acl = acl + xa[i] * xb[i];
 #pragma unroll
@@ -308,9 +317,10 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 }
 
 
-// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form -- measured K0 at 256 / 1024 / 2048 / 4096 streams: 24 / 26 / 35 / 66 us
-// against 55 / 55 / 55 / 59 us lane = stream: its 12.5 KB of LDS per wave limit a CU to 12 waves)
-#define RN_HP_ONE_MAX 3072
+// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form.  Round 5, 6.9 KB of LDS per wave -- 16 waves per CU, so 4,096 streams
+// are one round: K0 at 1024 / 2048 / 3072 / 4096 / 6144 / 8192 streams 33 / 38 / 48 / 60 / 80 / 99 us against 72 / 72 / 68 / 75 / 78 / 86 us lane =
+// stream (one slow box, one call); with 12.5 KB it was 66 against 59 us at 4,096 and the switch sat at 3,072)
+#define RN_HP_ONE_MAX 5120
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
 #else
