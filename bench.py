@@ -71,7 +71,7 @@ KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "netw
 # the batch sizes at which the library switches kernels (it honours the same environment variables)
 NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "16384"))
 NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
-HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "5120"))
+HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "3072"))  # (pipelined calls; 5120 for one-frame calls: hp_kernel.hip)
 K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))
 K1_MULTI_MIN_STREAMS = 6144
 K3_FEW_MAX_STREAMS = 256
@@ -205,8 +205,13 @@ def pmc_record(kernel: str, n_streams: int, model: str = "default"):
         with open(os.path.join(ROOT, "profiles", "pmc_by_streams.json")) as f:
             allsets = json.load(f)
         sets = allsets.get(model) if model != "default" and allsets.get(model) else allsets["by_streams"]
-        k = sets[min(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n)))]
-        return k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", "").replace("_w8", ""))
+        # (the nearest set that HAS the kernel: which form of a kernel a batch size runs also depends on the schedule of the pass)
+        for n in sorted(sets, key=lambda n: (abs(math.log2(int(n) / n_streams)), -int(n))):
+            k = sets[n]
+            r = k.get(kernel) or k.get(kernel.replace("_lean", "").replace("_single", "").replace("_w8", ""))
+            if r:
+                return r
+        return None
     except Exception:
         return None
 

@@ -329,7 +329,7 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     {
       TimedLaunch t(b, 3);
       b->cur_hp[f & 7] = t.on ? t.stop() : (pipelined ? b->own_hp[f & 7] : nullptr);
-      HIP_OK(rn_launch_hp(&b->g, d_in + buf(f) * N * RN_FRAME_SIZE * esz, s16, (b->ring_slot + f) % RN_RING_SLOTS, sc, t.start(),
+      HIP_OK(rn_launch_hp(&b->g, d_in + buf(f) * N * RN_FRAME_SIZE * esz, s16, ((b->ring_slot + f) % RN_RING_SLOTS) | (pipelined ? 512 : 0), sc, t.start(),
                           b->cur_hp[f & 7]));
     }
     if (hk && hk->after_hp(f, sc)) return -1;

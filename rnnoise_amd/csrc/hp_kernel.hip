@@ -321,13 +321,21 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 // are one round: K0 at 1024 / 2048 / 3072 / 4096 / 6144 / 8192 streams 33 / 38 / 48 / 60 / 80 / 99 us against 72 / 72 / 68 / 75 / 78 / 86 us lane =
 // stream (one slow box, one call); with 12.5 KB it was 66 against 59 us at 4,096 and the switch sat at 3,072)
 #define RN_HP_ONE_MAX 5120
+#define RN_HP_ONE_MAX_PIPELINED 3072
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
 #else
 #define rn_hp_slp_kernel rn_hp_kernel
 #endif
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
-  static const int one_max = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : RN_HP_ONE_MAX; }();  // (A/B runs)
+  // bit 9 of `slot` (batch.cpp): the call is one frame of a PIPELINED multi-frame call -- this kernel then runs on a side stream beside the
+  // analysis and network kernels of other frames, where 4,096 waves with 6.9 KB of LDS each crowd them (4,096 streams: 0.197 against
+  // 0.181 ms per step) while 64 lane-per-stream waves without LDS do not: the switch stays at 3,072 there; alone on the machine (one
+  // frame per call: 0.280 against 0.291 ms) the one-wave form wins up to RN_HP_ONE_MAX
+  static const int one_max_env = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : -1; }();  // (A/B runs)
+  const bool beside_others = slot & 512;
+  slot &= 511;
+  const int one_max = one_max_env >= 0 ? one_max_env : (beside_others ? RN_HP_ONE_MAX_PIPELINED : RN_HP_ONE_MAX);
   if (g->n_streams <= one_max) {
     RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16, RnRows{});
     return hipGetLastError();
