@@ -276,6 +276,11 @@ int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
   hipStream_t st = p->comb.stream[k];
   HIP_OK(rn_launch_hp_rows(&b->g, &rows, st));
+  // $RNNOISE_AMD_TEST_FAIL_GROUP=<n> (tests): the n-th launch group of the process "fails" here -- AFTER its high-pass has been queued,
+  // which is the case that leaves a row's pitch ring one frame ahead of the host-side slot counters
+  static const long fail_at = env_int("RNNOISE_AMD_TEST_FAIL_GROUP", -1);
+  static std::atomic<long> n_groups{0};
+  if (n_groups.fetch_add(1) == fail_at) return -1;
   HIP_OK(rn_launch_analysis_rows(&b->g, &b->tb, &rows, st));
   HIP_OK(rn_launch_nn_rows(&b->g, &b->m, &b->tb, &rows, st));
   HIP_OK(rn_launch_synthesis_rows(&b->g, &b->tb, &rows, st));

@@ -136,6 +136,36 @@ print("CRC", zlib.crc32(y.tobytes()))
     assert r.returncode == 0 and f"CRC {zlib.crc32(np.ascontiguousarray(want['out'][:, :3]).tobytes())}" in r.stdout, r.stdout + r.stderr
 
 
+def test_a_failed_launch_group_restarts_its_states_from_zero(blob_default, tmp_path):
+    """a launch group that fails after its high-pass has run leaves the row's pitch ring one frame ahead of the host-side slot
+    counters.  The frame comes back zeroed (VAD 0), and from the next call on the state is a FRESH one (what rnnoise_init leaves):
+    its output equals the oracle started at that frame -- not a stream running one ring slot off"""
+    code = r"""
+import sys, lzma, numpy as np
+sys.path.insert(0, %r)
+from rnnoise_amd import capi, synth
+m = capi.Model(lzma.decompress(open(%r, "rb").read()))
+st = capi.DenoiseState(m)
+x = synth.stream_pcm(5, 9).astype(np.float32).reshape(9, 480)
+out = np.stack([st.process_frame(x[t])[0] for t in range(9)])
+np.save(%r, out)
+"""
+    blob_path = os.path.join(ROOT, "tests", "golden", "default.blob.xz")
+    out_path = str(tmp_path / "out.npy")
+    # (group 0 is frame 0, ...: the 4th group of the process is this state's frame 3)
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, blob_path, out_path)], capture_output=True, text=True,
+                       env=dict(os.environ, RNNOISE_AMD_TEST_FAIL_GROUP="3"), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "returning a zeroed frame" in r.stderr and "restarts from zero" in r.stderr, r.stderr
+    got = np.load(out_path)
+    x = synth.stream_pcm(5, 9).astype(np.float32).reshape(9, 480)
+    before = Oracle(blob_default).run(x[:3])
+    assert_bits_equal(got[:3], before["out"], "frames before the failure")
+    assert not got[3].any()
+    after = Oracle(blob_default).run(x[4:])       # a fresh state fed frames 4 ..
+    assert_bits_equal(got[4:], after["out"], "frames after the restart")
+
+
 def test_caller_memory_states_interleaved(model, blob_default):
     """rnnoise_get_size() + rnnoise_init() on caller memory (rnnoise.h:57,71): self-contained POD, may be copied"""
     L = capi.lib()
