@@ -217,7 +217,8 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     return !e ? 0 : (!strcmp(e, "one") ? 1 : (!strcmp(e, "sdma") ? 3 : 2));
   }();
   const bool one_copy_stream = (copy_mode_env == 1 || copy_mode_env == 2) ? copy_mode_env == 1 : s16;
-  Sdma *sd = (copy_mode_env == 3 || copy_mode_env == 0) ? sdma_get(b, in) : nullptr;
+  // (a call's copies are all queued while its kernels are: the count words' source ring must not wrap inside one call)
+  Sdma *sd = ((copy_mode_env == 3 || copy_mode_env == 0) && n_frames <= Sdma::SEQ / 2) ? sdma_get(b, in) : nullptr;
   // per call: the signals of its frames (reused from call to call: the previous call ended with every copy complete)
   struct FrameSig { hsa_signal_t hp_read, k3_done, up, up_flag, dn, dn_flag; uint64_t dn_target; };
   std::vector<FrameSig> fs;
