@@ -27,8 +27,11 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
   // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
   const int apply_hp = mode & 1, in_s16 = mode & 2;
-  const int s = blockIdx.x * WAVE + threadIdx.x;
-  if (s >= g.n_streams) return;
+  // bits 12-13: streams per wave = 64 >> k.  The kernel is bound by how many loads its waves keep in flight (one wave per SIMD at 64 streams
+  // per wave and 65,536 streams: each lane's HBM round trips are its own), not by issue: half-empty waves are twice as many waves
+  const int spw = WAVE >> ((mode >> 12) & 3);
+  const int s = blockIdx.x * spw + threadIdx.x;
+  if ((int)threadIdx.x >= spw || s >= g.n_streams) return;
   // (race hunt, $RNNOISE_AMD_HP_AB: 256 = drain the wave's stores before the pitch ring is read back, 512 = raised issue
   //  priority, 1024 = drain the tap stores before the wave ends)
   if (mode & 512) __builtin_amdgcn_s_setprio(3);
@@ -322,6 +325,7 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 // stream (one slow box, one call); with 12.5 KB it was 66 against 59 us at 4,096 and the switch sat at 3,072)
 #define RN_HP_ONE_MAX 5120
 #define RN_HP_ONE_MAX_PIPELINED 3072
+#define RN_HP_SPW 64  // streams per wave of the lane = stream kernel
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
 #else
@@ -346,8 +350,15 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
 #else
   const bool slp = false;
 #endif
-  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + WAVE - 1) / WAVE), dim3(WAVE), 0, st, e0, done, *g,
-            static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab);
+  // $RNNOISE_AMD_HP_SPW = 64 | 32 | 16 streams per wave (A/B; default below)
+  static const int spw_shift = [] {
+    const char *e = getenv("RNNOISE_AMD_HP_SPW");
+    const int v = e ? atoi(e) : RN_HP_SPW;
+    return v == 16 ? 2 : (v == 32 ? 1 : 0);
+  }();
+  const int spw = WAVE >> spw_shift;
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + spw - 1) / spw), dim3(WAVE), 0, st, e0, done, *g,
+            static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {
