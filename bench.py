@@ -450,6 +450,9 @@ def bench_rank(a) -> dict | None:
     gpu_index = 0 if share else local_rank
     dev = torch.device("cpu") if stub else torch.device("cuda", gpu_index)
     if not stub:
+        if gpu_index >= torch.cuda.device_count():
+            sys.exit(f"bench.py: rank {rank} (local rank {local_rank}) needs GPU {gpu_index}, but this node shows {torch.cuda.device_count()} "
+                     f"device(s): start one rank per visible GPU (or RNNOISE_AMD_BENCH_SHARE_DEVICE=1 to test the rank path on one)")
         torch.cuda.set_device(gpu_index)
     pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch)
     dist, data_group, collective, collective_error = None, None, None, None
