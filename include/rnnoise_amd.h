@@ -61,8 +61,11 @@ RNNOISE_EXPORT int rnnoise_batch_reset(RNNoiseBatch *b);
 /* Host buffers; synchronous.  vad and gains may be NULL.  in may alias out. 0 / -1.
  * Pinned host memory (hipHostMalloc / hipHostRegister) is read and written by DMA in place, frame by frame, through a
  * six-slot ring in HBM beside ONE pipelined multi-frame device call: a call pays one frame's upload before and one frame's
- * download after its kernels whatever its length (use 16 frames or more per call when throughput matters).  Pageable
- * memory goes through the library's pinned bounce buffers in ~32 MB chunks, two in flight. */
+ * download after its kernels whatever its length (use 16 frames or more per call when throughput matters).  Where the runtime
+ * offers two free copy engines, uploads and downloads run on two NAMED SDMA engines at once (underneath HIP; DESIGN section 4,
+ * $RNNOISE_AMD_HOSTIO_COPY): 65,536 streams 30.9 M frames/s with int16 PCM, 21.2 M with floats.  Pageable
+ * memory goes through the library's pinned bounce buffers in ~32 MB chunks, two in flight.  A call that fails part of the way
+ * drains the device and resets the batch (every stream back to its initial state) before it returns -1. */
 RNNOISE_EXPORT int rnnoise_batch_process(RNNoiseBatch *b, float *out, const float *in, float *vad, float *gains,
                                          int n_frames);
 
