@@ -342,7 +342,17 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     const hsa_signal_t last = fs[(size_t)n_frames - 1].dn_flag;
     const uint64_t give_up = 30ull * 1000000000ull;
     if (hsa_signal_wait_scacquire(last, HSA_SIGNAL_CONDITION_LT, 1, give_up, HSA_WAIT_STATE_BLOCKED) >= 1) {
-      fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: the copy engines did not finish within 30 s\n");
+      // a copy that never completes leaves streams parked on the count words for ever: release them by hand (both counts past
+      // anything this call waits for), give the mode up for this batch, drain, reset
+      fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: the copy engines did not finish within 30 s; falling back to the runtime's copies\n");
+      for (FrameSig &q : fs) {
+        if (q.hp_read.handle) hsa_signal_store_screlease(q.hp_read, 0);
+        if (q.k3_done.handle) hsa_signal_store_screlease(q.k3_done, 0);
+      }
+      const uint64_t past[2] = {~0ull >> 1, ~0ull >> 1};
+      (void)hipMemcpy(&sd->d_flags[0], &past[0], 8, hipMemcpyHostToDevice);
+      (void)hipMemcpy(&sd->d_flags[32], &past[1], 8, hipMemcpyHostToDevice);
+      sd->ok = false;
       (void)hipDeviceSynchronize();
       (void)rnnoise_batch_reset(b);
       return -1;
@@ -358,6 +368,11 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
       }
       for (FrameSig &q : fs)
         if (q.dn_flag.handle && q.dn_target) (void)hsa_signal_wait_scacquire(q.dn_flag, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+      // (and streams parked on a count that a copy which was never queued would have written)
+      const uint64_t past = ~0ull >> 1;
+      (void)hipMemcpy(&sd->d_flags[0], &past, 8, hipMemcpyHostToDevice);
+      (void)hipMemcpy(&sd->d_flags[32], &past, 8, hipMemcpyHostToDevice);
+      sd->ok = false;  // (the counts no longer mean anything: this batch goes on with the runtime's copies)
     }
     (void)hipDeviceSynchronize();
     fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: a GPU step failed inside the call; the batch has been reset\n");
