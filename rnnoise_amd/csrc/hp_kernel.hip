@@ -22,7 +22,13 @@
 #ifndef RN_HP_KERNEL_NAME
 #define RN_HP_KERNEL_NAME rn_hp_kernel
 #endif
-extern "C" __global__ void __launch_bounds__(WAVE)
+#ifndef RN_HP_BLK
+#define RN_HP_BLK 8   // float4 per block and stream: 8 = one 128-byte line
+#endif
+#ifndef RN_HP_ATTR
+#define RN_HP_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(WAVE) RN_HP_ATTR
 RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
   // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
@@ -42,7 +48,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
   // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
   // filtered: with one wave per SIMD nothing else hides the HBM round trip
-  constexpr int BLK = 8;  // float4 per block
+  constexpr int BLK = RN_HP_BLK;  // float4 per block
   float4 cur[BLK], nxt[BLK];
   const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
   auto load4 = [&](int idx) -> float4 {
@@ -103,7 +109,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
     // pitch_buf in blocks of 32 floats (8 float4); ring0 and the ring size are multiples of 32, so a block never
     // straddles the wrap; the next block is requested before this one is consumed
     auto block = [&](int b, float4 (&dst)[BLK]) {
-      int p = ring0 + 32 * b;
+      int p = ring0 + 4 * BLK * b;
       p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
       const float4 *src = reinterpret_cast<const float4 *>(ring + p);
 #pragma unroll
@@ -113,10 +119,10 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
     float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
     float prev = 0;                          // pitch_buf[4c-1]
     block(0, nxt);
-    for (int b = 0; b < RN_PITCH_BUF_SIZE / 32; b++) {
+    for (int b = 0; b < RN_PITCH_BUF_SIZE / (4 * BLK); b++) {
 #pragma unroll
       for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-      if (b + 1 < RN_PITCH_BUF_SIZE / 32) block(b + 1, nxt);
+      if (b + 1 < RN_PITCH_BUF_SIZE / (4 * BLK)) block(b + 1, nxt);
 #pragma unroll
       for (int j = 0; j < BLK; j++) {
         const int c = b * BLK + j;
@@ -326,6 +332,8 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 #define RN_HP_ONE_MAX 5120
 #define RN_HP_ONE_MAX_PIPELINED 3072
 #define RN_HP_SPW 64  // streams per wave of the lane = stream kernel
+#define RN_HP_LEAN_MIN 32768
+extern "C" __global__ void rn_hp_lean_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_lean.hip
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
 #else
@@ -357,7 +365,13 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
     return v == 16 ? 2 : (v == 32 ? 1 : 0);
   }();
   const int spw = WAVE >> spw_shift;
-  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + spw - 1) / spw), dim3(WAVE), 0, st, e0, done, *g,
+  // the lean form (hp_lean.hip: 16-sample blocks, at most 64 VGPRs) inside pipelined calls: a wave of it fits a SIMD BESIDE four
+  // analysis waves (4 x 112 + 64 = 512 registers) instead of taking the place of one ($RNNOISE_AMD_HP_LEAN = 0 | 1, A/B)
+  // measured, each pair inside one call: 65,536 streams 35.9 -> 36.1 M frames/s (+0.5 %; the high-pass itself 0.45 -> 0.33 ms inside the
+  // pipeline), sparser blob 32,768: +0.9 %, 16,384: -2.2 % -- so from RN_HP_LEAN_MIN streams up
+  static const int lean_env = [] { const char *e = getenv("RNNOISE_AMD_HP_LEAN"); return e ? atoi(e) : -1; }();
+  const bool lean = (lean_env >= 0 ? lean_env != 0 : g->n_streams >= RN_HP_LEAN_MIN) && beside_others && !slp;
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : (lean ? rn_hp_lean_kernel : rn_hp_kernel), dim3((g->n_streams + spw - 1) / spw), dim3(WAVE), 0, st, e0, done, *g,
             static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
   return hipGetLastError();
 }
