@@ -202,7 +202,9 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   float *r_vad = reinterpret_cast<float *>(r_out + RING * slot_pcm), *r_g = reinterpret_cast<float *>(reinterpret_cast<char *>(r_vad) + RING * slot_vad);
   FrameIoHooks hk;
   hk.ring = RING;
-  // Copies.  int16 frames: uploads and downloads ALTERNATE ON ONE COPY STREAM (io.down), in the order the frame pipeline asks
+  // Copies.  Default: the two named copy engines above (mode sdma).  The runtime's own copies remain as the fallback (no two free
+  // engines, no hipStreamWaitValue64, calls longer than the count ring, a batch whose engines once failed) and for A/B runs:
+  // int16 frames: uploads and downloads ALTERNATE ON ONE COPY STREAM (io.down), in the order the frame pipeline asks
   // for them: each then finds the DMA engine free.  With two copies in flight the runtime executes one of them as a blit kernel
   // (256 workgroups x 512 lanes) whose PCIe-bound stores stall what runs beside it -- the analysis kernel took 2.3 ms instead
   // of 1.1 (rocprofv3 kernel + memory-copy trace) -- and a copy stream per direction plus the pipeline's three streams is more
@@ -210,8 +212,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   // 2 x 63 MB in 2.2 ms, just above the kernels' time: 28.0 M frames/s either way (profiles/r4_hostio_modes.txt).
   // float frames (2 x 126 MB per step) are bound by the link whatever the kernels do, and there both directions at once win:
   // uploads ride on the high-pass stream, downloads keep the copy stream -- 19.9 M frames/s against 14.6 M.
-  // $RNNOISE_AMD_HOSTIO_COPY = one | hp forces a mode (A/B runs).
-  // $RNNOISE_AMD_HOSTIO_COPY = one | hp | sdma forces a mode (A/B runs); sdma: the explicit copy engines above.
+  // $RNNOISE_AMD_HOSTIO_COPY = one | hp | sdma forces a mode (A/B runs); profiles/r5_hostio_sdma.txt has the three side by side.
   static const int copy_mode_env = [] {
     const char *e = getenv("RNNOISE_AMD_HOSTIO_COPY");
     return !e ? 0 : (!strcmp(e, "one") ? 1 : (!strcmp(e, "sdma") ? 3 : 2));
@@ -241,7 +242,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
       q.up_flag = sd->take(1);
       q.dn = sd->take(1 + (vad ? 1 : 0) + (gains ? 1 : 0));
       q.dn_flag = sd->take(1);
-      if (!q.dn_flag.handle) return -1;
+      if (!q.hp_read.handle || !q.k3_done.handle || !q.up.handle || !q.up_flag.handle || !q.dn.handle || !q.dn_flag.handle) return -1;
       // upload(f) on the upload engine, once high-pass(f - RING) has read the slot; the count of landed uploads behind it
       const hsa_signal_t *dep = f >= RING ? &fs[(size_t)(f - RING)].hp_read : nullptr;
       HSA_OK(hsa_amd_memory_async_copy_on_engine(r_in + (size_t)(f % RING) * fsz, sd->gpu, static_cast<const char *>(p_in) + (size_t)f * fsz, a_in, fsz,
@@ -366,8 +367,10 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
         if (q.hp_read.handle) hsa_signal_store_screlease(q.hp_read, 0);
         if (q.k3_done.handle) hsa_signal_store_screlease(q.k3_done, 0);
       }
-      for (FrameSig &q : fs)
-        if (q.dn_flag.handle && q.dn_target) (void)hsa_signal_wait_scacquire(q.dn_flag, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+      for (FrameSig &q : fs)  // (in order on one engine: the first download that does not land in 2 s ends the waiting)
+        if (q.dn_flag.handle && q.dn_target &&
+            hsa_signal_wait_scacquire(q.dn_flag, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) >= 1)
+          break;
       // (and streams parked on a count that a copy which was never queued would have written)
       const uint64_t past = ~0ull >> 1;
       (void)hipMemcpy(&sd->d_flags[0], &past, 8, hipMemcpyHostToDevice);
