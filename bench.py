@@ -448,6 +448,9 @@ def bench_rank(a) -> dict | None:
     # over gloo, since RCCL refuses two ranks on one device; the line says so ("shared_device": true) and is not a scaling number
     share = os.environ.get("RNNOISE_AMD_BENCH_SHARE_DEVICE") == "1" and not stub
     gpu_index = 0 if share else local_rank
+    if not stub and not share and local_rank > 0 and torch.cuda.device_count() == 1 and any(
+            os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        gpu_index = 0  # (a launcher that masks the devices per rank: each rank sees its own GPU as device 0)
     dev = torch.device("cpu") if stub else torch.device("cuda", gpu_index)
     if not stub:
         if gpu_index >= torch.cuda.device_count():
