@@ -249,3 +249,29 @@ def test_bench_with_two_ranks_on_one_device():
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / 8192 - 1) < 0.01
     assert d["parity"]["bit_identical"] is True and d["config"]["outputs_sane"] is True
     assert "cpu_baseline" not in d
+
+
+def test_bench_falls_back_to_gloo_when_rccl_refuses():
+    """The real RCCL in the failure path of bench.py's collectives (open_collectives): two ranks whose launcher shows each of them ONE
+    device -- the same one (HIP_VISIBLE_DEVICES=0) -- both ask RCCL for a communicator, RCCL refuses ("Duplicate GPU detected"), every
+    rank votes over the gloo control group, and the job runs to its line on gloo: "collective": "gloo-fallback" with the first error
+    text, the aggregate over both ranks, parity green.  What the first multi-GPU run does if its communicator cannot be built."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0", RNNOISE_AMD_BENCH_DATA_TIMEOUT="30", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RNNOISE_AMD_BENCH_SHARE_DEVICE", "RNNOISE_AMD_BENCH_DATA_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "4096", "--steps", "4",
+                        "--warmup", "2", "--repeats", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    if d["collective"] == "rccl":
+        pytest.skip("this RCCL accepts two ranks on one device: nothing to fall back from")
+    assert d["collective"] == "gloo-fallback" and d["collective_error"], d
+    assert d["n_gpus"] == 2 and len(d["value_by_rank"]) == 2
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / 8192 - 1) < 0.01
+    assert d["parity"]["bit_identical"] is True and d["config"]["outputs_sane"] is True
