@@ -231,6 +231,17 @@ def test_bad_state_returns_a_zeroed_frame_instead_of_aborting():
     assert v == 0.0 and not x.any()
 
 
+def test_host_fed_soak_on_the_named_copy_engines():
+    """tools/soak_hostio.py, short: 10 calls of 16 int16 frames at 65,536 streams and 10 calls of 12 float frames at 32,768 from pinned
+    memory on the default copy mode (uploads and downloads on two named copy engines, ordered against the kernels by count words and
+    release kernels) -- every ring slot reused ~25 times; after every call all replicas equal and the first block bit-identical to
+    the oracle.  (300 calls each: profiles/r5_soak_hostio.txt)"""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("RNNOISE_AMD_HOSTIO_COPY", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_hostio.py"), "10"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.count("(0 bad calls") == 2, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("pinned", [False, True, "s16"])
 def test_host_fed_path_chunks_in_flight(model, blob_default, pinned):
     """rnnoise_batch_process: 8192 streams x 12 frames from pageable memory (6 chunks of 32 MB through the double-buffered
