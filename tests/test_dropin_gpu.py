@@ -231,6 +231,41 @@ def test_bad_state_returns_a_zeroed_frame_instead_of_aborting():
     assert v == 0.0 and not x.any()
 
 
+def test_c_threads_through_the_combiner_give_the_oracles_bits(blob_default, tmp_path):
+    """tools/configs0_mt.c in check mode -- plain C threads, no interpreter lock in the way: 64 threads over 300 rnnoise_create()d
+    states, 200 frames each; state k is fed the deterministic signal k % 7 and checksums every output sample and VAD value.  All
+    states of a signal agree, and the seven checksums are the ORACLE's for the same signals: no frame lost, repeated or delivered
+    to the wrong row by the combiner.  (1,000 frames, up to 1,024 states and 128 threads: profiles/r5_combiner_stress.txt)"""
+    exe, blob_path = str(tmp_path / "configs0_mt"), str(tmp_path / "default.blob")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "configs0_mt.c"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "rnnoise_amd"), "-l:librnnoise_amd.so", "-Wl,-rpath," + os.path.join(ROOT, "rnnoise_amd"), "-lpthread"],
+                   check=True, capture_output=True, text=True)
+    with open(blob_path, "wb") as f:
+        f.write(blob_default)
+    frames = 200
+    r = subprocess.run([exe, blob_path, "64", str(frames - 100), "300", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "every state equal to its siblings" in r.stdout, r.stdout + r.stderr
+    got = r.stdout.split("checksums")[1].split()
+    M32, M64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF
+    want = []
+    for k in range(7):
+        g = (977 * k + 1) & M32
+        x = np.empty((frames, 480), np.float32)
+        for t in range(frames):
+            for i in range(480):
+                g = (g * 1664525 + 1013904223) & M32
+                x[t, i] = float((g >> 18) - 8192)
+        ref = Oracle(blob_default).run(x)
+        h = 0xcbf29ce484222325
+        out, vad = ref["out"].view(np.uint32), ref["vad"].view(np.uint32)
+        for t in range(frames):
+            for u in out[t].tolist():
+                h = ((h ^ u) * 0x100000001b3) & M64
+            h = ((h ^ int(vad[t])) * 0x100000001b3) & M64
+        want.append(f"{h:016x}")
+    assert got == want
+
+
 def test_host_fed_soak_on_the_named_copy_engines():
     """tools/soak_hostio.py, short: 10 calls of 16 int16 frames at 65,536 streams and 10 calls of 12 float frames at 32,768 from pinned
     memory on the default copy mode (uploads and downloads on two named copy engines, ordered against the kernels by count words and
