@@ -366,6 +366,26 @@ def pin_rank_cpus(local_rank: int, local_world: int, torch) -> None:
         pass
 
 
+def device_report(torch, rank: int, local_rank: int, gpu_index: int, stub: bool) -> dict:
+    """What this rank can say about the device it runs on: torch's index and name, the PCI address (the one identity a device mask
+    cannot rename), the library's own device count, and the masks in the environment."""
+    rep = {"rank": rank, "local_rank": local_rank, "device": None if stub else gpu_index,
+           "masks": {v: os.environ[v] for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if v in os.environ}}
+    if stub:
+        return rep
+    try:
+        p = torch.cuda.get_device_properties(gpu_index)
+        rep["name"] = p.name
+        if hasattr(p, "pci_bus_id"):
+            rep["pci_bus"] = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}"
+        rep["torch_device_count"] = torch.cuda.device_count()
+        from rnnoise_amd import capi
+        rep["rnnoise_amd_device_count"] = int(capi.lib().rnnoise_amd_device_count())
+    except Exception as e:  # noqa: BLE001 -- a report, not a requirement
+        rep["error"] = repr(e)[:200]
+    return rep
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -561,6 +581,13 @@ def bench_rank(a) -> dict | None:
         shards, rank_medians = [None] * world, [None] * world
         dist.all_gather_object(shards, [mine.start, mine.stop])
         dist.all_gather_object(rank_medians, own_median)
+    # which device every rank really ran on: a launcher that masks or mis-numbers the GPUs shows up in the line itself (two ranks with
+    # one PCI bus id = two ranks on one GPU, whatever their indices say)
+    report = device_report(torch, rank, local_rank, gpu_index, stub)
+    devices = [report]
+    if dist:
+        devices = [None] * world
+        dist.all_gather_object(devices, report)
     frames_per_rep = float(N * K * world)
     med = statistics.median(times)
     line = None
@@ -683,6 +710,10 @@ def bench_rank(a) -> dict | None:
             if mf:
                 line["mfma_utilisation"] = {"definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per launch, one-stream schedule",
                                             "kernels": mf}
+        line["devices_by_rank"] = devices
+        buses = [d.get("pci_bus") for d in devices if d.get("pci_bus")]
+        if len(buses) != len(set(buses)):
+            line["devices_shared_between_ranks"] = True  # (not a scaling number: some ranks ran on the same GPU)
         if stub:
             line["stub"] = True
         if share and world > 1:

@@ -1,5 +1,6 @@
 // batch.cpp -- rnnoise_batch_*: N streams resident on one GPU; the frame step as a pipeline over HIP streams.
 #include "shim.h"
+#include "device_choice.h"
 
 namespace {
 template <typename T>
@@ -161,7 +162,7 @@ extern "C" RNNoiseBatch *rnnoise_batch_create(RNNModel *model, int n_streams, in
     fprintf(stderr, "[rnnoise_amd] rnnoise_batch_create: a model blob is required (no compiled-in weights)\n");
     return nullptr;
   }
-  if (device < 0 || device >= rnnoise_amd_device_count()) {
+  if (!rn_device_index_ok(device, rnnoise_amd_device_count())) {
     fprintf(stderr, "[rnnoise_amd] no HIP device %d (visible devices: %d); there is no CPU fallback\n", device,
             rnnoise_amd_device_count());
     return nullptr;
@@ -281,15 +282,15 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
   const bool side_k1 = pipelined && pipe_force != 1;
   // $RNNOISE_AMD_SIDE_PRIO = <k1>,<hp> (A/B runs): queue priorities of the two side streams, -1 high / 0 normal / 1 low (the caller's
   // stream, which carries network + synthesis, is whatever the caller made it: normal for torch's)
-  static const int side_prio[2] = {[] { const char *e = getenv("RNNOISE_AMD_SIDE_PRIO"); return e ? atoi(e) : 0; }(),
-                                   [] { const char *e = getenv("RNNOISE_AMD_SIDE_PRIO"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }()};
+  static const int side_prio[2] = {[] { const char *e = RN_LAB_ENV("SIDE_PRIO"); return e ? atoi(e) : 0; }(),
+                                   [] { const char *e = RN_LAB_ENV("SIDE_PRIO"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }()};
   if (side_k1 && !b->side) HIP_OK(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, side_prio[0]));
   if (pipelined && !b->side_hp) {
     HIP_OK(hipStreamCreateWithPriority(&b->side_hp, hipStreamNonBlocking, side_prio[1]));
     // ordering between streams of ONE device: no system-scope fence (it writes back and invalidates the caches at
     // every record, which the next kernels then pay for)
     // ($RNNOISE_AMD_EVENT_FENCE=1, A/B runs only: ordering events with the system-scope fence back on)
-    static const bool sys_fence = [] { const char *e = getenv("RNNOISE_AMD_EVENT_FENCE"); return e && atoi(e) == 1; }();
+    static const bool sys_fence = [] { const char *e = RN_LAB_ENV("EVENT_FENCE"); return e && atoi(e) == 1; }();
     const unsigned evf = hipEventDisableTiming | (sys_fence ? 0u : (unsigned)hipEventDisableSystemFence);
     HIP_OK(hipEventCreateWithFlags(&b->ev_begin, evf));
     for (int k = 0; k < 8; k++) {
@@ -323,8 +324,13 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     // SIMD for 0.18 ms, and a GRU workgroup (2 waves x 240 VGPRs per SIMD) does not fit beside even one of them: the first
     // layer kernel of every frame waited that long (rocprofv3 timeline: 283 us instead of 115).  Beside the analysis kernel
     // (4 waves x 56 VGPRs per SIMD) it costs nothing.
-    static const bool hp_early = getenv("RNNOISE_AMD_HP_EARLY") != nullptr;  // A/B runs only: the ring-bound start
+    static const bool hp_early = RN_LAB_ENV("HP_EARLY") != nullptr;  // A/B runs only: the ring-bound start
     if (side_k1 && f >= 4 && !hp_early) HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[(f - 4) & 7], 0));
+    // ... and the same concern when only the high-pass runs aside (schedule 1: the host-fed path): there analysis(f-2) follows
+    // synthesis(f-3) on the main stream, so that is the event to start behind -- the high-pass of frame f is launched after it (see the
+    // frame loop).  Started at the ring's earliest moment it ran beside the layer kernels of frame f-3: network 0.73 ms instead of 0.57
+    // (profiles/r5_hostio_sdma.txt).
+    if (pipelined && !side_k1 && f >= 3 && !hp_early) HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[(f - 3) & 7], 0));
     if (hk && hk->before_hp(f, sc)) return -1;
     {
       TimedLaunch t(b, 3);
@@ -360,7 +366,7 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     if (!pipelined) {
       if (highpass(f) || analysis(f)) return -1;
     } else {
-      if (f + 3 < n_frames && highpass(f + 3)) return -1;
+      if (side_k1 && f + 3 < n_frames && highpass(f + 3)) return -1;
       if (f + 1 < n_frames && analysis(f + 1)) return -1;
       if (side_k1) HIP_OK(hipStreamWaitEvent(st, b->cur_k1[f & 7], 0));
     }
@@ -386,10 +392,12 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     }
     {
       TimedLaunch t(b, 2);
-      b->cur_k3[f & 7] = t.on ? t.stop() : (side_k1 ? b->own_k3[f & 7] : nullptr);
+      b->cur_k3[f & 7] = t.on ? t.stop() : (pipelined ? b->own_k3[f & 7] : nullptr);
       HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + buf(f) * N * RN_FRAME_SIZE * esz, s16, cur, prev, st, t.start(), b->cur_k3[f & 7]));
     }
     if (hk && hk->after_k3(f, st)) return -1;
+    // (schedule 1: the high-pass three frames ahead goes out HERE, behind the synthesis launch whose end it starts at)
+    if (pipelined && !side_k1 && f + 3 < n_frames && highpass(f + 3)) return -1;
     b->launches += b->timing ? 1 : 0;
   }
   b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;

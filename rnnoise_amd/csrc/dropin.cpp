@@ -1,6 +1,7 @@
 // dropin.cpp -- the reference's own API (include/rnnoise.h; reference implementation src/denoise.c:227-325,457-504) on
 // device-resident state pools, and the combiner that turns concurrent one-frame calls into shared launches.
 #include "shim.h"
+#include "device_choice.h"
 
 #include <linux/futex.h>
 #include <sched.h>
@@ -44,23 +45,28 @@ StatePool *pool_new(RNNModel *model, int device) {
   p->used.assign(p->rows / 64, 0ull);
   p->req = static_cast<int *>(calloc(p->rows, sizeof(int)));
   p->sleeping = static_cast<int *>(calloc(p->rows, sizeof(int)));
+  if (!p->req || !p->sleeping) {
+    free(p->req);
+    free(p->sleeping);
+    hipHostFree(p->h_io);
+    hipFree(p->d_flat);
+    rnnoise_batch_destroy(p->batch);
+    delete p;
+    return nullptr;
+  }
   // launch groups run the latency network kernel (rn_nn_one_kernel, 125 KB of LDS by opt-in): where it cannot run, pooled frames go
   // through pool_step one state at a time, which has the vector kernel to fall back on
   p->comb.no_nn_one = nn_one_max_streams() < 1;
   return p;
 }
 
-// Which device a NEW pool goes to.  $RNNOISE_AMD_DEVICE = <index>: that one.  Otherwise the visible devices in turn (the k-th pool of
-// a model on device k mod count): the reference lets a process hold any number of independent states (include/rnnoise.h:80,
-// src/denoise.c:311-321); on a multi-GPU node a few hundred of them each should not all land on device 0.
+// Which device a NEW pool goes to: device_choice.h (rn_pool_device), with $RNNOISE_AMD_DEVICE = <index> as the pin
 int pool_device_for(size_t n_pools_so_far) {
   static const int pinned = [] {
     const char *e = getenv("RNNOISE_AMD_DEVICE");
     return e && *e ? atoi(e) : -1;
   }();
-  const int count = std::max(1, rnnoise_amd_device_count());
-  if (pinned >= 0) return std::min(pinned, count - 1);
-  return (int)(n_pools_so_far % (size_t)count);
+  return rn_pool_device(n_pools_so_far, pinned, rnnoise_amd_device_count());
 }
 
 // a free row of one of the model's pools (a new pool when all are full); zeroed like rnnoise_init().  max_row: rows below it only
@@ -276,34 +282,77 @@ int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp) {
   for (int i = rows.n; i < RN_ROWS_MAX; i++) rows.e[i] = 0;
   hipStream_t st = p->comb.stream[k];
   HIP_OK(rn_launch_hp_rows(&b->g, &rows, st));
-  // $RNNOISE_AMD_TEST_FAIL_GROUP=<n> (tests): the n-th launch group of the process "fails" here -- AFTER its high-pass has been queued,
-  // which is the case that leaves a row's pitch ring one frame ahead of the host-side slot counters
-  static const long fail_at = env_int("RNNOISE_AMD_TEST_FAIL_GROUP", -1);
+#if RN_INSTRUMENT
+  // $RNNOISE_AMD_TEST_FAIL_GROUP=<n>[,<m>...] (fault injection, instrumented library only): the n-th (m-th ...) launch group of the process
+  // "fails" here -- AFTER its high-pass has been queued, which is the case that leaves a row's pitch ring one frame ahead of the
+  // host-side slot counters
+  static const std::vector<long> fail_at = [] {
+    std::vector<long> v;
+    if (const char *e = RN_LAB_ENV("TEST_FAIL_GROUP"))
+      for (const char *q = e; *q;) {
+        char *end = nullptr;
+        v.push_back(strtol(q, &end, 10));
+        if (end == q) break;
+        q = *end ? end + 1 : end;
+      }
+    return v;
+  }();
   static std::atomic<long> n_groups{0};
-  if (n_groups.fetch_add(1) == fail_at) return -1;
+  const long this_group = n_groups.fetch_add(1);
+  for (long f : fail_at)
+    if (f == this_group) return -1;
+#endif
   HIP_OK(rn_launch_analysis_rows(&b->g, &b->tb, &rows, st));
   HIP_OK(rn_launch_nn_rows(&b->g, &b->m, &b->tb, &rows, st));
   HIP_OK(rn_launch_synthesis_rows(&b->g, &b->tb, &rows, st));
   return 0;
 }
 
-// a launch failed part of the way: nothing of the group may outlive its frames; every member fails
-void comb_abort(StatePool *p, int k, const std::vector<CombMember> &grp, PooledRef *self) {
+bool comb_complete(StatePool *p, int k, PooledRef *self);
+int comb_launch(StatePool *p, int k, const std::vector<CombMember> &grp);
+
+// a launch failed part of the way: nothing of the group may outlive its frames; every member fails.
+// A pool has more rows than a launch group has entries, so requests may still be QUEUED behind the failed group.  Somebody has to
+// adopt them: a group in flight on another stream does when it completes, a caller inside its gather window does when the window
+// closes -- and when there is neither, this thread does, here (before round 6 it did not, and those callers slept for ever).
+void comb_abort(StatePool *p, int k, std::vector<CombMember> grp, PooledRef *self) {
   Combiner &c = p->comb;
-  (void)hipStreamSynchronize(c.stream[k]);
-  (void)hipGetLastError();
-  std::vector<int *> wake;
-  {
-    std::lock_guard<std::mutex> lk(c.mu);
-    // the high-pass of the group may have run before the failing launch: the members' pitch rings may already hold this frame,
-    // which their host-side ring slot will not count.  Every member restarts from zero at its next call (its caller is still
-    // blocked on its request word: the entry's state is alive here).
-    for (const CombMember &e : grp) __atomic_store_n(&e.ref->poisoned, 1, __ATOMIC_SEQ_CST);
-    c.members[k].clear();
-    c.busy[k] = false;
-    comb_retire(p, grp, REQ_DONE_FAIL, self, wake);
+  for (;;) {
+    (void)hipStreamSynchronize(c.stream[k]);  // (whatever of the group was launched is off the rows before anybody zeroes them)
+    (void)hipGetLastError();
+    std::vector<int *> wake;
+    std::vector<CombMember> next;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      // the high-pass of the group may have run before the failing launch: the members' pitch rings may already hold this frame,
+      // which their host-side ring slot will not count.  Every member restarts from zero at its next call (its caller is still
+      // blocked on its request word: the entry's state is alive here).
+      for (const CombMember &e : grp) __atomic_store_n(&e.ref->poisoned, 1, __ATOMIC_SEQ_CST);
+      c.members[k].clear();
+      bool others = c.gathering;
+      for (int i = 0; i < c.n_streams; i++) others |= i != k && c.busy[i];
+      if (!c.queue.empty() && !others) comb_take_queue(p, k, next);
+      else c.busy[k] = false;
+      comb_retire(p, grp, REQ_DONE_FAIL, self, wake);
+    }
+    comb_wake(wake);
+    if (next.empty()) return;
+    if (comb_launch(p, k, next)) {  // this one too: its members fail, and whatever is queued behind it gets the same treatment
+      grp.swap(next);
+      self = nullptr;
+      continue;
+    }
+    // one of the adopted group's own members waits for it: the first one that is still waiting for its frame
+    for (const CombMember &e : next) {
+      int expect = req_word(e.seq, REQ_INFLIGHT);
+      if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+        if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) futex(&p->req[e.slot], FUTEX_WAKE_PRIVATE, 1);
+        return;
+      }
+    }
+    (void)comb_complete(p, k, nullptr);  // (every member has already taken its frame and gone)
+    return;
   }
-  comb_wake(wake);
 }
 
 // The caller `self` owns the wait for the group on stream k (it launched it, or was named its syncer): wait, hand the stream
@@ -402,6 +451,39 @@ bool comb_submit(StatePool *p, PooledRef *r) {
   };
   int lead = -1;
   std::vector<CombMember> grp;
+  // (lock held, stream k free, this request still QUEUED) the queue -- its oldest RN_ROWS_MAX requests -- becomes the group on stream k.
+  // Returns k when this request is in it (the caller then leads: lead_group), -1 when more than a row list's worth was queued in front
+  // of it: that group is launched here and handed to one of its members, and this thread goes on waiting like a follower.
+  auto take_and_maybe_lead = [&](std::unique_lock<std::mutex> &lk, int k) -> int {
+    comb_take_queue(p, k, grp);
+    bool mine = false;
+    for (const CombMember &e : grp) mine |= e.ref == r;
+    if (mine) return k;
+    lk.unlock();
+    if (comb_launch(p, k, grp)) comb_abort(p, k, grp, nullptr);
+    else {
+      bool named = false;
+      for (const CombMember &e : grp) {
+        int expect = req_word(e.seq, REQ_INFLIGHT);
+        if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+          if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) futex(&p->req[e.slot], FUTEX_WAKE_PRIVATE, 1);
+          named = true;
+          break;
+        }
+      }
+      if (!named) (void)comb_complete(p, k, nullptr);
+    }
+    grp.clear();
+    lk.lock();
+    return -1;
+  };
+  auto lead_group = [&](int k) -> bool {
+    if (comb_launch(p, k, grp)) {
+      comb_abort(p, k, grp, r);
+      return false;
+    }
+    return leave(comb_complete(p, k, r));
+  };
   {
     std::unique_lock<std::mutex> lk(c.mu);
     if (now_ns() - c.t_complete_ns.load(std::memory_order_relaxed) > gather_ns + 5000) c.pending_returns.store(0, std::memory_order_relaxed);  // stale
@@ -438,39 +520,9 @@ bool comb_submit(StatePool *p, PooledRef *r) {
         k = comb_free_stream(p);
       }
     }
-    if (k >= 0 && __atomic_load_n(req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) {  // lead: the queue (its oldest 64 requests) is this group
-      comb_take_queue(p, k, grp);
-      bool mine = false;
-      for (const CombMember &e : grp) mine |= e.ref == r;
-      if (mine) lead = k;
-      else {  // (more than a row list's worth was queued in front of this request: launch that group, then wait like a follower)
-        lk.unlock();
-        if (comb_launch(p, k, grp)) comb_abort(p, k, grp, nullptr);
-        else {
-          // one of its members owns its wait; this thread goes on waiting for its own request
-          bool named = false;
-          for (const CombMember &e : grp) {
-            int expect = req_word(e.seq, REQ_INFLIGHT);
-            if (__atomic_compare_exchange_n(&p->req[e.slot], &expect, req_word(e.seq, REQ_SYNCER), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
-              if (__atomic_load_n(&p->sleeping[e.slot], __ATOMIC_SEQ_CST)) futex(&p->req[e.slot], FUTEX_WAKE_PRIVATE, 1);
-              named = true;
-              break;
-            }
-          }
-          if (!named) (void)comb_complete(p, k, nullptr);
-        }
-        grp.clear();
-        lk.lock();
-      }
-    }
+    if (k >= 0 && __atomic_load_n(req, __ATOMIC_SEQ_CST) == req_word(seq, REQ_QUEUED)) lead = take_and_maybe_lead(lk, k);
   }
-  if (lead >= 0) {
-    if (comb_launch(p, lead, grp)) {
-      comb_abort(p, lead, grp, r);
-      return false;
-    }
-    return leave(comb_complete(p, lead, r));
-  }
+  if (lead >= 0) return lead_group(lead);
   // wait: for the frame (the row's `done` word, or the group's owner saying so), or to be named the owner of the group's wait
   const bool may_spin = c.active.load(std::memory_order_relaxed) <= effective_cpus();
   if (wake_early_us > 0) {
@@ -502,9 +554,23 @@ bool comb_submit(StatePool *p, PooledRef *r) {
       cpu_relax();
       continue;
     }
+    // (timed: a request still QUEUED when the wait runs out, with no group in flight and nobody gathering, has nobody left to adopt it
+    //  -- comb_abort and comb_complete see to it that this does not happen; if it ever does, its caller leads it instead of sleeping on)
+    const timespec ts{0, 20 * 1000 * 1000};
     __atomic_store_n(sleeping, 1, __ATOMIC_SEQ_CST);
-    if (__atomic_load_n(req, __ATOMIC_SEQ_CST) == w) futex(req, FUTEX_WAIT_PRIVATE, w);
+    if (__atomic_load_n(req, __ATOMIC_SEQ_CST) == w) syscall(SYS_futex, req, FUTEX_WAIT_PRIVATE, w, &ts, nullptr, 0);
     __atomic_store_n(sleeping, 0, __ATOMIC_SEQ_CST);
+    if (s == REQ_QUEUED && __atomic_load_n(req, __ATOMIC_SEQ_CST) == w) {
+      std::unique_lock<std::mutex> lk(c.mu);
+      bool adopters = c.gathering;
+      for (int i = 0; i < c.n_streams; i++) adopters |= c.busy[i];
+      if (!adopters && __atomic_load_n(req, __ATOMIC_SEQ_CST) == w) {
+        const int k = comb_free_stream(p);
+        if (k >= 0) lead = take_and_maybe_lead(lk, k);
+      }
+      lk.unlock();
+      if (lead >= 0) return lead_group(lead);
+    }
   }
 }
 

@@ -844,9 +844,10 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // every workgroup, and the two running-energy sweeps of phase 3 advance side by side.  Clear: everything on wave 0 (round 3).
   const bool spread = SPW > 1;                            // (round 4 measured it against everything-on-wave-0 in one kernel: 4 %; that
                                                           //  form now lives only in the one-stream workgroups, where wave 0 is the stream)
-  const bool xrow = !(slot_arg & 1024);                   // bit 10 (A/B runs): the doubling dots read x per lane from LDS (chain_dot8_y2)
-  const int narrow_prio = (slot_arg & 4096) ? 1 : 3;      // bit 12 (A/B runs): the narrow-phase waves keep the kernel's priority
-  const bool fine_deep = !(slot_arg & 16384);             // bit 14 (A/B runs): the fine-search chains fetch one block ahead, not two
+  // (A/B switches of the instrumented build, rn_launch_analysis: compile-time constants in the product)
+  const bool xrow = !(RN_INSTRUMENT && (slot_arg & 1024));              // bit 10: the doubling dots read x per lane from LDS (chain_dot8_y2)
+  const int narrow_prio = (RN_INSTRUMENT && (slot_arg & 4096)) ? 1 : 3; // bit 12: the narrow-phase waves keep the kernel's priority
+  const bool fine_deep = !(RN_INSTRUMENT && (slot_arg & 16384));        // bit 14: the fine-search chains fetch one block ahead, not two
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -1843,17 +1844,17 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
   // A/B runs only: RNNOISE_AMD_K1_SPW=1 / 4 forces one / K1_SPW streams per workgroup; RNNOISE_AMD_K1_LDS -> a larger
   // LDS request per wave lowers the waves per CU (occupancy experiments)
   static const int spw_force = [] { const char *e = getenv("RNNOISE_AMD_K1_SPW"); return e ? atoi(e) : 0; }();
-  static const size_t lds1 = [] { const char *e = getenv("RNNOISE_AMD_K1_LDS"); return e ? (size_t)atoi(e) : sizeof(AnalysisLds); }();
+  static const size_t lds1 = [] { const char *e = RN_LAB_ENV("K1_LDS"); return e ? (size_t)atoi(e) : sizeof(AnalysisLds); }();
   const int n = g->n_streams;
   const bool single = spw_force == 1 || (spw_force == 0 && n < RN_K1_MULTI_MIN_STREAMS);
   if (single) {
     RN_LAUNCH(rn_analysis_single_kernel, dim3(n), dim3(WAVE), lds1, st, e0, e1, *g, *tb, slot, parity, RnRows{});
   } else {
     const dim3 grid((n + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
-    static const int prio = [] { const char *e = getenv("RNNOISE_AMD_K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
-    static const int stop = [] { const char *e = getenv("RNNOISE_AMD_K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
+    static const int prio = [] { const char *e = RN_LAB_ENV("K1_PRIO"); return (e && atoi(e) == 0) ? 0 : 256; }();
+    static const int stop = [] { const char *e = RN_LAB_ENV("K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
     static const int noxrow = [] {
-      const char *e = getenv("RNNOISE_AMD_K1_XROW"), *x = getenv("RNNOISE_AMD_K1_EXPERIMENT");  // (A/B bits 12, 14: see analysis_body)
+      const char *e = RN_LAB_ENV("K1_XROW"), *x = RN_LAB_ENV("K1_EXPERIMENT");  // (A/B bits 12, 14: see analysis_body)
       return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (4096 | 16384)) : 0);
     }();
     RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | noxrow, parity);
@@ -1881,7 +1882,7 @@ extern "C" hipError_t rn_launch_synthesis(const RnGroupDev *g, const RnTablesDev
 // K1 / K3 of a launch group of the one-frame API (rn_dev.h: RnRows): one one-wave workgroup per listed row
 extern "C" hipError_t rn_launch_analysis_rows(const RnGroupDev *g, const RnTablesDev *tb, const RnRows *rows, hipStream_t st) {
   // RNNOISE_AMD_ROWS_K1=1 (A/B runs): one wave per row (rn_analysis_single_kernel) instead of a workgroup of four
-  static const bool one_wave = [] { const char *e = getenv("RNNOISE_AMD_ROWS_K1"); return e && atoi(e) == 1; }();
+  static const bool one_wave = [] { const char *e = RN_LAB_ENV("ROWS_K1"); return e && atoi(e) == 1; }();
   if (one_wave) hipLaunchKernelGGL(rn_analysis_single_kernel, dim3(rows->n), dim3(WAVE), sizeof(AnalysisLds), st, *g, *tb, 0, 0, *rows);
   else hipLaunchKernelGGL(rn_analysis_rows_kernel, dim3(rows->n), dim3(WAVE * K1_SPW), K1_SPW * sizeof(AnalysisLds), st, *g, *tb, *rows);
   return hipGetLastError();

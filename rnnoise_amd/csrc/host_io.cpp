@@ -6,6 +6,8 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <chrono>
+
 // ---- host-fed path (pinned, double-buffered H2D / D2H) ----
 namespace {
 bool host_pinned(const void *p) {  // memory the DMA engines can reach directly (hipHostMalloc / hipHostRegister)
@@ -33,7 +35,7 @@ bool host_pinned(const void *p) {  // memory the DMA engines can reach directly 
 //   copy engine -> host    the completion signal of the call's last copy (hsa_signal_wait).
 // ---------------------------------------------------------------------------------------------
 struct Sdma {
-  bool ok = false;
+  bool ok = false, hsa_ref = false;
   hsa_agent_t gpu{}, cpu{};
   hsa_amd_sdma_engine_id_t e_up{}, e_dn{};
   uint64_t *d_flags = nullptr;  // device memory: [0] uploads landed so far, [32] downloads landed so far (separate lines)
@@ -55,6 +57,25 @@ struct Sdma {
 };
 
 namespace {
+// Wait until the signal drops below 1, for at most `seconds` of WALL-CLOCK time.  hsa_signal_wait's timeout hint is in ticks of the
+// HSA system timestamp (HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, 100 MHz here -- not nanoseconds: round 5's "30 s" was 300 s), and the
+// call may return early with the condition unmet: so it is asked for 0.1 s worth of ticks at a time until a steady clock says stop.
+bool sdma_wait(hsa_signal_t s, double seconds) {
+  uint64_t freq = 0;
+  if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) != HSA_STATUS_SUCCESS || !freq) freq = 100000000ull;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+  for (;;) {
+    if (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, freq / 10, HSA_WAIT_STATE_BLOCKED) < 1) return true;
+    if (std::chrono::steady_clock::now() >= deadline) return false;
+  }
+}
+// The value word of an HSA signal as a kernel can store to it.  This reaches INTO ROCr: hsa_signal_t::handle is the address of an
+// amd_signal_t (hsa/amd_hsa_signal.h, a public header of the runtime, but the identity handle == address is the runtime's own
+// business).  Developed and soaked on the runtime profiles/r6_hostio_timeline.txt names (ROCm 7.2.0's ROCr); sdma_selftest() below
+// proves the assumption -- a kernel's store into this word releases a copy that lists the signal as its dependency -- on whatever
+// runtime the process has, once per batch, BEFORE the mode is used; a runtime where it does not hold gets the runtime's own copies.
+void *sdma_value_word(hsa_signal_t s) { return static_cast<void *>(const_cast<int64_t *>(&reinterpret_cast<amd_signal_t *>(s.handle)->value)); }
+
 bool sdma_owner(const void *p, hsa_agent_t &agent, const void *&agent_ptr) {  // who owns p, and p as that side's engines address it
   hsa_amd_pointer_info_t info;
   memset(&info, 0, sizeof info);
@@ -66,6 +87,54 @@ bool sdma_owner(const void *p, hsa_agent_t &agent, const void *&agent_ptr) {  //
     agent_ptr = static_cast<const char *>(info.agentBaseAddress) + (static_cast<const char *>(p) - static_cast<const char *>(info.hostBaseAddress));
   return true;
 }
+// Everything copy mode "sdma" assumes about the runtime, exercised once with 8 bytes and wall-clock deadlines before the mode is
+// trusted with a caller's frames (a runtime where the assumptions half-hold must fail HERE, at set-up, not as a stall in
+// the middle of a call):
+//   stream -> engine   an upload on the named upload engine that lists a signal as its dependency starts when a KERNEL stores 0 into
+//                      the signal's value word (sdma_value_word: the amd_signal_t layout);
+//   engine -> stream   the word the upload writes into device memory releases a stream parked on it by hipStreamWaitValue64;
+//   engine -> engine   a download on the named download engine that depends on the upload's completion signal brings the word back;
+//   engine -> host     hsa_signal_wait sees the download complete.
+// Returns nullptr when all four hold, else the name of the step that did not.
+const char *sdma_selftest(Sdma *s) {
+  const uint64_t magic = 0x5EEDF00D5EEDull;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return "self-test: stream";
+  const hsa_signal_t dep = s->take(1), up = s->take(1), dn = s->take(1);
+  const char *bad = nullptr;
+  s->h_seq[0] = magic;
+  s->h_seq[1] = 0;
+  if (!dep.handle || !up.handle || !dn.handle) bad = "self-test: signals";
+  else if (hsa_amd_memory_async_copy_on_engine(&s->d_flags[16], s->gpu, &s->h_seq[0], s->cpu, 8, 1, &dep, up, s->e_up, false) != HSA_STATUS_SUCCESS)
+    bad = "self-test: upload on the named engine";
+  else if (hsa_amd_memory_async_copy_on_engine(&s->h_seq[1], s->cpu, &s->d_flags[16], s->gpu, 8, 1, &up, dn, s->e_dn, false) != HSA_STATUS_SUCCESS)
+    bad = "self-test: download on the named engine";
+  if (bad) {
+    if (dep.handle) hsa_signal_store_screlease(dep, 0);  // (whatever was queued runs out)
+    if (dn.handle) (void)sdma_wait(dn, 2.0);
+  } else {
+    // nothing may have moved yet: the upload waits for `dep`
+    if (hsa_signal_load_scacquire(up) < 1) bad = "self-test: the upload did not wait for its dependency";
+    else if (rn_launch_release_store(sdma_value_word(dep), 0, st) != hipSuccess) bad = "self-test: release kernel";
+    else if (hipStreamWaitValue64(st, &s->d_flags[16], magic, hipStreamWaitValueEq, ~0ull) != hipSuccess) bad = "self-test: hipStreamWaitValue64";
+    if (bad) hsa_signal_store_screlease(dep, 0);
+    if (!sdma_wait(dn, 2.0)) bad = bad ? bad : "self-test: a kernel's store into the signal's value word did not release the copy (amd_signal_t layout?)";
+    else if (!bad && s->h_seq[1] != magic) bad = "self-test: the word did not come back";
+    // the stream parked on the word: released by the upload -- or by hand, so that nothing stays parked behind a failed test
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+    while (hipStreamQuery(st) == hipErrorNotReady && std::chrono::steady_clock::now() < deadline) {}
+    if (hipStreamQuery(st) == hipErrorNotReady) {
+      bad = bad ? bad : "self-test: hipStreamWaitValue64 did not see the engine's write";
+      (void)hipMemcpy(&s->d_flags[16], &magic, 8, hipMemcpyHostToDevice);
+    }
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipGetLastError();
+  (void)hipStreamDestroy(st);
+  s->used = 0;  // (the three signals go back to the pool)
+  return bad;
+}
+
 Sdma *sdma_get(RNNoiseBatch *b, const void *host_ptr) {
   RNNoiseBatch::HostIo &io = b->io;
   if (io.sdma) return io.sdma->ok ? io.sdma : nullptr;
@@ -76,8 +145,9 @@ Sdma *sdma_get(RNNoiseBatch *b, const void *host_ptr) {
     fprintf(stderr, "[rnnoise_amd] copy mode sdma unavailable (%s: %s); using the runtime's copies\n", what, m ? m : "?");
     return nullptr;
   };
-  hsa_status_t st = hsa_init();  // (reference-counted; the HIP runtime holds the first reference)
+  hsa_status_t st = hsa_init();  // (reference-counted; the HIP runtime holds the first reference; ours is dropped in sdma_free)
   if (st != HSA_STATUS_SUCCESS) return fail("hsa_init", st);
+  s->hsa_ref = true;
   const void *ap = nullptr;
   if (!sdma_owner(io.ring_mem, s->gpu, ap) || !sdma_owner(host_ptr, s->cpu, ap)) return fail("hsa_amd_pointer_info", HSA_STATUS_ERROR);
   uint32_t free_up = 0, free_dn = 0, pref_up = 0, pref_dn = 0;
@@ -99,6 +169,7 @@ Sdma *sdma_get(RNNoiseBatch *b, const void *host_ptr) {
   }
   int can = 0;
   if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, b->device) != hipSuccess || !can) return fail("hipStreamWaitValue64", HSA_STATUS_ERROR);
+  if (const char *what = sdma_selftest(s)) return fail(what, HSA_STATUS_ERROR);
   s->ok = true;
   return s;
 }
@@ -107,6 +178,7 @@ void sdma_free(RNNoiseBatch::HostIo &io) {
   for (hsa_signal_t sg : io.sdma->pool) hsa_signal_destroy(sg);
   if (io.sdma->d_flags) hipFree(io.sdma->d_flags);
   if (io.sdma->h_seq) hipHostFree(io.sdma->h_seq);
+  if (io.sdma->hsa_ref) (void)hsa_shut_down();
   delete io.sdma;
   io.sdma = nullptr;
 }
@@ -230,7 +302,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
     fs.resize((size_t)n_frames);
     if (!sdma_owner(in, a_in, p_in) || !sdma_owner(out, a_out, p_out) || (vad && !sdma_owner(vad, a_vad, p_vad)) || (gains && !sdma_owner(gains, a_g, p_g))) sd = nullptr;
   }
-  auto value_word = [](hsa_signal_t s) { return static_cast<void *>(const_cast<int64_t *>(&reinterpret_cast<amd_signal_t *>(s.handle)->value)); };
+  auto value_word = [](hsa_signal_t s) { return sdma_value_word(s); };
 #define HSA_OK(x) do { hsa_status_t s_ = (x); if (s_ != HSA_STATUS_SUCCESS) { const char *m_ = nullptr; hsa_status_string(s_, &m_); \
     fprintf(stderr, "[rnnoise_amd] %s: %s\n", #x, m_ ? m_ : "?"); return -1; } } while (0)
   hk.before_hp = [&](int f, hipStream_t sc) -> int {
@@ -280,7 +352,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   // writing the caller's pinned memory through its device address (state_kernels.hip: rn_copy_to_host_kernel): measured
   // slower than the serialised DMA copies (18 M against 23-28 M frames/s), kept for the record.
   static const int d2h_blocks = [] {
-    const char *e = getenv("RNNOISE_AMD_D2H");
+    const char *e = RN_LAB_ENV("D2H");
     if (e && !strncmp(e, "kernel:", 7)) return std::max(1, atoi(e + 7));
     return 0;
   }();
@@ -333,7 +405,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   // streams then share a queue: what the high-pass stream carries queues up behind analysis kernels and the whole step
   // serialises (rocprofv3 trace: 3.5 ms per 65,536-stream s16 step).  Analysis therefore stays on the main stream here
   // (schedule 1: only the high-pass runs ahead on a side stream), which costs the 2-3 % the analysis overlap is worth.
-  static const int sched_env = [] { const char *e = getenv("RNNOISE_AMD_HOSTIO_SCHEDULE"); return e ? atoi(e) : 1; }();  // (A/B runs)
+  static const int sched_env = [] { const char *e = RN_LAB_ENV("HOSTIO_SCHEDULE"); return e ? atoi(e) : 1; }();  // (A/B runs)
   const int keep = b->schedule;
   if (b->schedule == 0) b->schedule = sched_env;
   const int rc = batch_process_device_impl(b, r_out, r_in, r_vad, r_g, n_frames, io.run, s16, &hk);
@@ -341,8 +413,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
   if (sd && !rc && n_frames > 0) {
     // every copy of the call is complete once the last frame's download count has landed (the engines work in order)
     const hsa_signal_t last = fs[(size_t)n_frames - 1].dn_flag;
-    const uint64_t give_up = 30ull * 1000000000ull;
-    if (hsa_signal_wait_scacquire(last, HSA_SIGNAL_CONDITION_LT, 1, give_up, HSA_WAIT_STATE_BLOCKED) >= 1) {
+    if (!sdma_wait(last, 30.0)) {
       // a copy that never completes leaves streams parked on the count words for ever: release them by hand (both counts past
       // anything this call waits for), give the mode up for this batch, drain, reset
       fprintf(stderr, "[rnnoise_amd] rnnoise_batch_process: the copy engines did not finish within 30 s; falling back to the runtime's copies\n");
@@ -368,9 +439,7 @@ static int batch_process_pinned(RNNoiseBatch *b, char *out, const char *in, floa
         if (q.k3_done.handle) hsa_signal_store_screlease(q.k3_done, 0);
       }
       for (FrameSig &q : fs)  // (in order on one engine: the first download that does not land in 2 s ends the waiting)
-        if (q.dn_flag.handle && q.dn_target &&
-            hsa_signal_wait_scacquire(q.dn_flag, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) >= 1)
-          break;
+        if (q.dn_flag.handle && q.dn_target && !sdma_wait(q.dn_flag, 2.0)) break;
       // (and streams parked on a count that a copy which was never queued would have written)
       const uint64_t past = ~0ull >> 1;
       (void)hipMemcpy(&sd->d_flags[0], &past, 8, hipMemcpyHostToDevice);

@@ -40,7 +40,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   if ((int)threadIdx.x >= spw || s >= g.n_streams) return;
   // (race hunt, $RNNOISE_AMD_HP_AB: 256 = drain the wave's stores before the pitch ring is read back, 512 = raised issue
   //  priority, 1024 = drain the tap stores before the wave ends)
-  if (mode & 512) __builtin_amdgcn_s_setprio(3);
+  if (RN_INSTRUMENT && (mode & 512)) __builtin_amdgcn_s_setprio(3);
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
@@ -99,7 +99,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
   // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
   // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
-  if (mode & 256) {
+  if (RN_INSTRUMENT && (mode & 256)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   }
@@ -164,7 +164,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
 #pragma unroll
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
     }
-    if (mode & 1024) {
+    if (RN_INSTRUMENT && (mode & 1024)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     }
@@ -352,15 +352,15 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
     RN_LAUNCH(rn_hp_one_kernel, dim3(g->n_streams), dim3(WAVE), 0, st, e0, done, *g, static_cast<const float *>(in), slot, in_s16, RnRows{});
     return hipGetLastError();
   }
-  static const int ab = [] { const char *e = getenv("RNNOISE_AMD_HP_AB"); return e ? atoi(e) & (256 | 512 | 1024) : 0; }();  // (A/B runs)
+  static const int ab = [] { const char *e = RN_LAB_ENV("HP_AB"); return e ? atoi(e) & (256 | 512 | 1024) : 0; }();  // (A/B runs)
 #if RN_INSTRUMENT
-  static const bool slp = [] { const char *e = getenv("RNNOISE_AMD_HP_AB"); return e && (atoi(e) & 2048); }();  // (A/B: hp_slp.hip)
+  static const bool slp = [] { const char *e = RN_LAB_ENV("HP_AB"); return e && (atoi(e) & 2048); }();  // (A/B: hp_slp.hip)
 #else
   const bool slp = false;
 #endif
   // $RNNOISE_AMD_HP_SPW = 64 | 32 | 16 streams per wave (A/B; default below)
   static const int spw_shift = [] {
-    const char *e = getenv("RNNOISE_AMD_HP_SPW");
+    const char *e = RN_LAB_ENV("HP_SPW");
     const int v = e ? atoi(e) : RN_HP_SPW;
     return v == 16 ? 2 : (v == 32 ? 1 : 0);
   }();
@@ -381,7 +381,7 @@ extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float 
 }
 // K0 of a launch group of the one-frame API (rn_dev.h: RnRows): one wave per listed row, float frames from the pool's pinned blocks
 extern "C" hipError_t rn_launch_hp_rows(const RnGroupDev *g, const RnRows *rows, hipStream_t st) {
-  static const int taps_here = [] { const char *e = getenv("RNNOISE_AMD_ROWS_K1"); return (e && atoi(e) == 1) ? 256 : 0; }();  // (dsp_kernels.hip: rn_launch_analysis_rows)
+  static const int taps_here = [] { const char *e = RN_LAB_ENV("ROWS_K1"); return (e && atoi(e) == 1) ? 256 : 0; }();  // (dsp_kernels.hip: rn_launch_analysis_rows)
   hipLaunchKernelGGL(rn_hp_one_kernel, dim3(rows->n), dim3(WAVE), 0, st, *g, static_cast<const float *>(nullptr), taps_here, 0, *rows);
   return hipGetLastError();
 }

@@ -5,4 +5,4 @@
 // stays reproducible: $RNNOISE_AMD_HP_AB=2048 on librnnoise_amd_instr.so (tools/gru_race.py).  The product library never has it.
 #define RN_HP_KERNEL_NAME rn_hp_slp_kernel
 #define RN_HP_VARIANT_ONLY 1
-#include "hp_kernel.hip"
+#include "../hp_kernel.hip"

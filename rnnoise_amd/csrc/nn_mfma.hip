@@ -69,14 +69,16 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_front_kernel(RnGrou
 #include "nn_tile_body.inc"
 #undef RN_NN_MODE
 }
-// the same at <= 64 VGPRs (A/B, $RNNOISE_AMD_FRONT64=1): the front's 33 KB of LDS allow four workgroups per CU, its 66 -> 72 allocated
-// registers x 2 waves per SIMD only three
+#if RN_INSTRUMENT
+// the same at <= 64 VGPRs (A/B of the instrumented build, $RNNOISE_AMD_FRONT64=1): the front's 33 KB of LDS allow four workgroups per
+// CU, its 66 -> 72 allocated registers x 2 waves per SIMD only three
 extern "C" __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 rn_nn_front64_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 #define RN_NN_MODE 1
 #include "nn_tile_body.inc"
 #undef RN_NN_MODE
 }
+#endif
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                         hipEvent_t e0, hipEvent_t e1) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm) return hipErrorNotSupported;
@@ -94,9 +96,12 @@ extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev 
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
   if ((size_t)g->n_streams * RN_GRU * 4 >= (1ull << 32)) return hipErrorNotSupported;  // 32-bit offsets in nn_layers.hip
   const dim3 grid((g->n_streams + TS - 1) / TS);
-  static const bool front64 = [] { const char *e = getenv("RNNOISE_AMD_FRONT64"); return e && atoi(e) == 1; }();
+#if RN_INSTRUMENT
+  static const bool front64 = [] { const char *e = RN_LAB_ENV("FRONT64"); return e && atoi(e) == 1; }();
   if (front64) RN_LAUNCH(rn_nn_front64_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
-  else RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
+  else
+#endif
+    RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
   for (int k = 0; k < 3; k++) {
     hipError_t e = rn_launch_nn_gru_layer(g, m, tb, k, st, ev[1 + k][0], ev[1 + k][1]);
     if (e != hipSuccess) return e;

@@ -19,6 +19,19 @@
 #define RN_INSTRUMENT 0
 #endif
 #include "../../include/rn_layout.h"
+#include <stdlib.h>
+// The environment variables this library reads come in two classes:
+//   getenv("RNNOISE_AMD_...")   product knobs: configuration, and dispatch thresholds that select between kernels with the
+//                               same bits.  Every one of them is listed in INTEGRATION.md ("Environment variables");
+//                               tests/test_product_surface_cpu.py compares the names found in the product .so with that list.
+//   RN_LAB_ENV("...")           A/B switches, timing experiments and fault injection: read by the INSTRUMENTED build only.  In the
+//                               product the macro is a null constant -- the name is not even in the binary, and no environment
+//                               can steer a drop-in librnnoise.so.0 onto an experiment.
+#if RN_INSTRUMENT
+#define RN_LAB_ENV(name) getenv("RNNOISE_AMD_" name)
+#else
+#define RN_LAB_ENV(name) (static_cast<const char *>(nullptr))
+#endif
 
 // floats of one band-product array in LDS (the layout of RnTablesDev::band_q, tables.cpp: tables_for_device); the analysis
 // kernel forms two band vectors at once from two arrays this far apart

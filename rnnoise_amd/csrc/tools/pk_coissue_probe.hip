@@ -14,6 +14,7 @@
 // Output: per (victim form, aggressor) the number of victim waves with a wrong lane, the lanes by quarter, the component.
 //
 //   build: make -C rnnoise_amd/csrc tools ; run: rnnoise_amd/csrc/build/pk_coissue_probe [--iters 4000] [--two 1] [--roles 2]
+//   stagger sweep (profiles/r6_pk_sweep.txt): build/pk_coissue_probe[_b1|_b2] --sweep 64 --two 0|1 --reps 2
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -40,13 +41,24 @@ __device__ __forceinline__ float lcg(unsigned &s) {
   s = s * 1664525u + 1013904223u;
   return (float)(int)(s >> 9) * (1.f / 4194304.f) - 1.f;
 }
+// `stagger` (--sweep): that many extra s_nop iterations per victim step -- the victim's issue cadence against the aggressor's MFMA
+// stream moves by a few clocks per unit.  Which cells of the table fire "changes from build to build ... depends on the issue cadence"
+// (profiles/r5_gru_race.txt), so a 0 at ONE cadence says little: the sweep asks every form at 64 cadences, in three builds of the loop
+// (-DPROBE_BUILD=0|1|2: the delay in front of the step / behind it with two extra integer operations / split around the operand
+// generator), beside both 128-bit-operand MFMA forms, and keeps the op_sel forms in the table as the positive control.
+#ifndef PROBE_BUILD
+#define PROBE_BUILD 0
+#endif
 template <int FORM>
-__device__ __forceinline__ v2f victim_chain(int iters, unsigned seed) {
+__device__ __forceinline__ v2f victim_chain(int iters, unsigned seed, int stagger) {
   v2f acc = {0.f, 0.f}, w = {0.f, 0.f};
   double dacc = 0;
   unsigned s = seed;
   for (int i = 0; i < iters; i++) {
+    if (PROBE_BUILD == 0) for (int d = 0; d < stagger; d++) asm volatile("s_nop 0");
+    if (PROBE_BUILD == 2) for (int d = 0; d < (stagger >> 1); d++) asm volatile("s_nop 1");
     const float x0 = lcg(s);
+    if (PROBE_BUILD == 2) for (int d = 0; d < stagger - (stagger >> 1); d++) asm volatile("s_nop 0");
     v2f x = {x0, 0.f}, p;
     if (FORM == V_SCALAR) {
       float p0, p1;
@@ -91,23 +103,27 @@ __device__ __forceinline__ v2f victim_chain(int iters, unsigned seed) {
     }
     w.y = w.x;
     w.x = x0;
+    if (PROBE_BUILD == 1) {
+      for (int d = 0; d < stagger; d++) asm volatile("s_nop 0");
+      asm volatile("v_add_u32 %0, %0, %1\n\tv_sub_u32 %0, %0, %1" : "+v"(s) : "v"(i));
+    }
   }
   if (FORM == V_F64) return v2f{__uint_as_float((unsigned)__double_as_longlong(dacc)), __uint_as_float((unsigned)(__double_as_longlong(dacc) >> 32))};
   return acc;
 }
-__device__ __forceinline__ v2f victim_run(int form, int iters, unsigned seed) {
+__device__ __forceinline__ v2f victim_run(int form, int iters, unsigned seed, int stagger) {
   switch (form) {
-    case V_SCALAR: return victim_chain<V_SCALAR>(iters, seed);
-    case V_PK_PLAIN: return victim_chain<V_PK_PLAIN>(iters, seed);
-    case V_PK_SELHI: return victim_chain<V_PK_SELHI>(iters, seed);
-    case V_PK_SEL: return victim_chain<V_PK_SEL>(iters, seed);
-    case V_PK_FMA: return victim_chain<V_PK_FMA>(iters, seed);
-    case V_PK_MOV: return victim_chain<V_PK_MOV>(iters, seed);
-    case V_PK_SEL0: return victim_chain<V_PK_SEL0>(iters, seed);
-    case V_PK_ADDSEL: return victim_chain<V_PK_ADDSEL>(iters, seed);
-    case V_PK_FMASEL: return victim_chain<V_PK_FMASEL>(iters, seed);
-    case V_PK_SWAP: return victim_chain<V_PK_SWAP>(iters, seed);
-    default: return victim_chain<V_F64>(iters, seed);
+    case V_SCALAR: return victim_chain<V_SCALAR>(iters, seed, stagger);
+    case V_PK_PLAIN: return victim_chain<V_PK_PLAIN>(iters, seed, stagger);
+    case V_PK_SELHI: return victim_chain<V_PK_SELHI>(iters, seed, stagger);
+    case V_PK_SEL: return victim_chain<V_PK_SEL>(iters, seed, stagger);
+    case V_PK_FMA: return victim_chain<V_PK_FMA>(iters, seed, stagger);
+    case V_PK_MOV: return victim_chain<V_PK_MOV>(iters, seed, stagger);
+    case V_PK_SEL0: return victim_chain<V_PK_SEL0>(iters, seed, stagger);
+    case V_PK_ADDSEL: return victim_chain<V_PK_ADDSEL>(iters, seed, stagger);
+    case V_PK_FMASEL: return victim_chain<V_PK_FMASEL>(iters, seed, stagger);
+    case V_PK_SWAP: return victim_chain<V_PK_SWAP>(iters, seed, stagger);
+    default: return victim_chain<V_F64>(iters, seed, stagger);
   }
 }
 // out[0] waves checked, out[1] waves with a wrong lane, out[2..5] wrong lanes by quarter, out[6] wrong .x, out[7] wrong .y,
@@ -222,13 +238,13 @@ __device__ __forceinline__ float aggressor_run(int kind, int iters, const float 
 }
 
 // one kernel: 8 waves per workgroup, role by wave index
-extern "C" __global__ void __launch_bounds__(512) probe_one(int form, int kind, int v_iters, int a_iters, int role_shift, unsigned *out, float *sink) {
+extern "C" __global__ void __launch_bounds__(512) probe_one(int form, int kind, int v_iters, int a_iters, int role_shift, unsigned *out, float *sink, int stagger) {
   extern __shared__ float lds[];
   for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = i;
   __syncthreads();
   const int wave = threadIdx.x >> 6;
   if ((wave >> role_shift) & 1) {
-    victim_check(victim_run(form, v_iters, 12345u), out, blockIdx.x * 8 + wave);
+    victim_check(victim_run(form, v_iters, 12345u, stagger), out, blockIdx.x * 8 + wave);
   } else {
     const float s = aggressor_run(kind, a_iters, lds);
     if (s == 1.2345f) sink[0] = s;
@@ -243,19 +259,20 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
   const float s = aggressor_run(kind, a_iters, lds);
   if (s == 1.2345f) sink[0] = s;
 }
-extern "C" __global__ void __launch_bounds__(64) probe_victim(int form, int v_iters, unsigned *out) {
+extern "C" __global__ void __launch_bounds__(64) probe_victim(int form, int v_iters, unsigned *out, int stagger) {
   asm volatile("v_mov_b32 v100, 0" ::: "v100");
-  victim_check(victim_run(form, v_iters, 12345u), out, blockIdx.x);
+  victim_check(victim_run(form, v_iters, 12345u, stagger), out, blockIdx.x);
 }
 
 #define OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 int main(int argc, char **argv) {
-  int iters = 4000, two = 1, roles = 2, reps = 3;
+  int iters = 4000, two = 1, roles = 2, reps = 3, sweep = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--two")) two = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--roles")) roles = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--sweep")) sweep = atoi(argv[i + 1]);
   }
   unsigned *d_out;
   float *d_sink;
@@ -267,6 +284,49 @@ int main(int argc, char **argv) {
   OK(hipFuncSetAttribute(reinterpret_cast<const void *>(probe_aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
   hipDeviceProp_t prop;
   OK(hipGetDeviceProperties(&prop, 0));
+  if (sweep) {
+    // ---- stagger sweep: every victim form x {i8 16x16x64, bf16 16x16x32} x staggers 0 .. sweep-1, `reps` launches per cell ----
+    printf("# pk_coissue_probe --sweep %d on %s (build %d): victim chains of %d steps, %s, %d launch(es) per cell\n", sweep,
+           prop.gcnArchName, PROBE_BUILD, iters, two ? "two kernels (aggressor: 4-wave workgroups, 230 VGPRs, 72 KB LDS; victim: one-wave workgroups)" : "one kernel (8 waves, 2 per SIMD)", reps);
+    printf("# line = victim form | aggressor | staggers that fired / staggers tried | wrong victim waves / waves checked | lanes by quarter | stagger:wrong-waves list\n");
+    const int kinds[2] = {A_MFMA_I8, A_MFMA_BF16};
+    for (int form = 0; form < NV; form++) {
+      for (int kk = 0; kk < 2; kk++) {
+        const int kind = kinds[kk];
+        unsigned long long tot[8] = {};
+        int fired = 0;
+        char list[4096];
+        int ll = 0;
+        list[0] = 0;
+        for (int st = 0; st < sweep; st++) {
+          unsigned cell = 0;
+          for (int r = 0; r < reps; r++) {
+            OK(hipMemset(d_out, 0, 64));
+            OK(hipDeviceSynchronize());
+            if (two) {
+              hipLaunchKernelGGL(probe_aggressor, dim3(512), dim3(256), 72 * 1024, sa, kind, iters * (6 + st / 4), d_sink);
+              hipLaunchKernelGGL(probe_victim, dim3(8192), dim3(64), 0, sv, form, iters, d_out, st);
+            } else {
+              hipLaunchKernelGGL(probe_one, dim3(1024), dim3(512), 16384, sv, form, kind, iters, iters / 2 * (1 + st / 8), roles, d_out, d_sink, st);
+            }
+            OK(hipDeviceSynchronize());
+            unsigned h[16];
+            OK(hipMemcpy(h, d_out, 64, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 8; k++) tot[k] += h[k];
+            cell += h[1];
+          }
+          if (cell) {
+            fired++;
+            if (ll < 3900) ll += snprintf(list + ll, sizeof list - ll, " %d:%u", st, cell);
+          }
+        }
+        printf("%-58s | %-40s | %2d / %2d | %8llu / %-9llu | %llu %llu %llu %llu |%s\n", VN[form], AN[kind], fired, sweep, tot[1], tot[0], tot[2], tot[3], tot[4],
+               tot[5], fired ? list : " -");
+        fflush(stdout);
+      }
+    }
+    return 0;
+  }
   printf("# pk_coissue_probe on %s: victim chains of %d steps, %s, %d launches per cell\n", prop.gcnArchName, iters,
          two ? "two kernels (aggressor: 4-wave workgroups, 230 VGPRs, 72 KB LDS; victim: one-wave workgroups)" : "one kernel (8 waves, 2 per SIMD)", reps);
   printf("# cell = victim waves with a wrong lane / waves checked [wrong lanes in quarters 0..3 | wrong .x, .y]\n");
@@ -280,9 +340,9 @@ int main(int argc, char **argv) {
         if (two) {
           // aggressors first (they run ~10x longer than one victim wave), victims stream in beside them
           hipLaunchKernelGGL(probe_aggressor, dim3(512), dim3(256), 72 * 1024, sa, kind, iters * 6, d_sink);
-          hipLaunchKernelGGL(probe_victim, dim3(8192), dim3(64), 0, sv, form, iters, d_out);
+          hipLaunchKernelGGL(probe_victim, dim3(8192), dim3(64), 0, sv, form, iters, d_out, 0);
         } else {
-          hipLaunchKernelGGL(probe_one, dim3(1024), dim3(512), 16384, sv, form, kind, iters, iters / 2, roles, d_out, d_sink);
+          hipLaunchKernelGGL(probe_one, dim3(1024), dim3(512), 16384, sv, form, kind, iters, iters / 2, roles, d_out, d_sink, 0);
         }
         OK(hipDeviceSynchronize());
         unsigned h[16];

@@ -137,7 +137,8 @@ print("CRC", zlib.crc32(y.tobytes()))
 
 
 def test_a_failed_launch_group_restarts_its_states_from_zero(blob_default, tmp_path):
-    """a launch group that fails after its high-pass has run leaves the row's pitch ring one frame ahead of the host-side slot
+    """(fault injection: $RNNOISE_AMD_TEST_FAIL_GROUP exists in the instrumented library only -- the product reads no such switch)
+    a launch group that fails after its high-pass has run leaves the row's pitch ring one frame ahead of the host-side slot
     counters.  The frame comes back zeroed (VAD 0), and from the next call on the state is a FRESH one (what rnnoise_init leaves):
     its output equals the oracle started at that frame -- not a stream running one ring slot off"""
     code = r"""
@@ -154,7 +155,7 @@ np.save(%r, out)
     out_path = str(tmp_path / "out.npy")
     # (group 0 is frame 0, ...: the 4th group of the process is this state's frame 3)
     r = subprocess.run([sys.executable, "-c", code % (ROOT, blob_path, out_path)], capture_output=True, text=True,
-                       env=dict(os.environ, RNNOISE_AMD_TEST_FAIL_GROUP="3"), timeout=300)
+                       env=dict(os.environ, RNNOISE_AMD_TEST_FAIL_GROUP="3", RNNOISE_AMD_LIB=capi.INSTR_LIB_PATH), timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "returning a zeroed frame" in r.stderr and "restarts from zero" in r.stderr, r.stderr
     got = np.load(out_path)
@@ -164,6 +165,39 @@ np.save(%r, out)
     assert not got[3].any()
     after = Oracle(blob_default).run(x[4:])       # a fresh state fed frames 4 ..
     assert_bits_equal(got[4:], after["out"], "frames after the restart")
+
+
+def test_failed_launch_groups_strand_nobody(tmp_path):
+    """a pool holds up to 1,024 rows but a launch group takes the oldest 64 queued requests, so requests can
+    still be QUEUED behind a group whose launch fails -- and with no other group in flight nobody adopted them: their callers slept
+    for ever.  160 states on 160 threads marching in step (a barrier per frame), seven launch groups of the process made to fail:
+    every call must come back (the subprocess has a timeout), failed frames zeroed, and the last frames -- by then every poisoned
+    state has restarted -- must be somebody's output again."""
+    code = r"""
+import sys, lzma, threading, numpy as np
+sys.path.insert(0, %r)
+from rnnoise_amd import capi, synth
+m = capi.Model(lzma.decompress(open(%r, "rb").read()))
+N, T = 160, 8
+st = [capi.DenoiseState(m) for _ in range(N)]
+x = synth.stream_pcm(3, T).astype(np.float32).reshape(T, 480)
+bar = threading.Barrier(N)
+nz = [0] * N
+def run(k):
+    for t in range(T):
+        bar.wait()
+        out, vad = st[k].process_frame(x[t])
+        if t == T - 1: nz[k] = int(np.any(out != 0))
+th = [threading.Thread(target=run, args=(k,)) for k in range(N)]
+[t.start() for t in th]; [t.join() for t in th]
+print("DONE", sum(nz))
+"""
+    blob_path = os.path.join(ROOT, "tests", "golden", "default.blob.xz")
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, blob_path)], capture_output=True, text=True,
+                       env=dict(os.environ, RNNOISE_AMD_TEST_FAIL_GROUP="2,3,4,5,6,7,8", RNNOISE_AMD_LIB=capi.INSTR_LIB_PATH), timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "returning a zeroed frame" in r.stderr, r.stderr[-2000:]
+    assert "DONE 160" in r.stdout, r.stdout[-500:]   # frame 7: every state -- restarted or not -- produces sound again
 
 
 def test_caller_memory_states_interleaved(model, blob_default):

@@ -77,6 +77,61 @@ def test_sparser_model_32768(blob_little, rcp_profile):
     _tiled_check(blob_little, 32768, (5, 1, 8), silent_stream=9)
 
 
+def _ragged_check(blob, N, calls, silent_stream):
+    """_tiled_check for a batch size that is NOT a multiple of anything: N = 32 q + r streams = q replicas of a 32-stream block and
+    the first r streams of one more.  Every kernel of the default schedule then has a partial unit at the end of its grid -- the
+    lane = stream high-pass a partial wave, the four-stream analysis workgroups a partial workgroup, the front kernel a partial
+    16-stream tile, the four-wave GRU layer kernel and the dense kernel a partial 64-stream group -- whose surplus lanes work on
+    clamped addresses and must store nothing.  Whole replicas are compared among themselves, the ragged tail with the head of
+    block 0, block 0 with the oracle; states are exported from the tail."""
+    import torch
+    T, q, r = sum(calls), N // 32, N % 32
+    assert r and N % 64 and N % 16 and N % 4
+    base = synth.batch_pcm(range(32), T)
+    base[:3, silent_stream] = 0
+    base[T - 5:T - 3, (silent_stream + 3) % 32] = 0
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(base).to(dev).repeat(1, q + 1, 1)[:, :N].contiguous()
+    d_out = torch.empty_like(d_in)
+    d_vad = torch.empty((T, N), device=dev)
+    d_gains = torch.empty((T, N, 32), device=dev)
+    m = capi.Model(blob)
+    b = capi.Batch(m, N)
+    assert b.set_nn_path(1) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    f = 0
+    for n in calls:
+        b.process_device(d_out[f].data_ptr(), d_in[f].data_ptr(), d_vad[f].data_ptr(), d_gains[f].data_ptr(), n, st)
+        f += n
+    torch.cuda.synchronize()
+    for name, t, w in (("pcm", d_out, 480), ("gains", d_gains, 32), ("vad", d_vad, 1)):
+        t = t.reshape(T, N, w).view(torch.int32)
+        whole = t[:, :32 * q].reshape(T, q, 32 * w)
+        assert bool((whole == whole[:, :1]).all().item()), f"replicated streams diverged ({name})"
+        assert bool((t[:, 32 * q:] == t[:, :r]).all().item()), f"the ragged tail differs from the head of block 0 ({name})"
+    out, gains, vad = d_out[:, :32].cpu().numpy(), d_gains[:, :32].cpu().numpy(), d_vad[:, :32].cpu().numpy()
+    del d_in, d_out, d_gains, d_vad
+    want = oracle_run(blob, base)
+    assert want["silence"][:, silent_stream].any() and not want["silence"][:, 0].any()
+    assert_bits_equal(out, want["out"], "pcm")
+    assert_bits_equal(gains, want["gains"], "gains")
+    assert_bits_equal(vad, want["vad"], "vad")
+    for s_ in (N - 1, N - r, N - r - 1, (N // 2 // 32) * 32 + silent_stream):   # the last stream, the tail's first, the last whole block's last
+        assert_bits_equal(b.export_state(s_), want["state"][s_ % 32], f"state of stream {s_}")
+    b.close()
+    m.close()
+
+
+@pytest.mark.rcp("host")
+@pytest.mark.parametrize("which", ["default", "little"])
+def test_ragged_40037_streams(blob_default, blob_little, which):
+    """VERDICT r5 Weak #1: the kernels that are the at-size defaults -- the four-wave rn_nn_gru_kernel (more 64-stream groups than CUs:
+    > 16,384 streams) and rn_hp_lean_kernel (>= 32,768 streams inside pipelined calls) -- on a batch with a partial tile (40,037 = 16 x
+    2,502 + 5), a partial group (64 x 625 + 37), a partial analysis workgroup and a partial high-pass wave; default and sparser blob,
+    default schedule, 14 frames as calls of 5 + 1 + 8.  Arithmetic under test: src/nnet.c:65-94, src/denoise.c:409-419."""
+    _ragged_check(blob_default if which == "default" else blob_little, 40037, (5, 1, 8), silent_stream=3)
+
+
 @pytest.mark.rcp("host")
 def test_16384_streams_on_the_host_profile(blob_default):
     """the smallest batch on the layer-wise network, on the profile a deployed process gets by default (this CPU's rcpps)"""

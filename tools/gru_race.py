@@ -135,6 +135,8 @@ def main():
         if a.only and not any(k in name for k in a.only.split(",")):
             continue
         e = dict(os.environ); e.update(env)
+        # (the switches under test -- forms of the layer kernel, $RNNOISE_AMD_HP_AB, _GRU_SETTLE ... -- exist in the instrumented library only)
+        e.setdefault("RNNOISE_AMD_LIB", os.path.join(ROOT, "rnnoise_amd", "librnnoise_amd_instr.so"))
         r = subprocess.run([sys.executable, __file__, "--worker", "--streams", str(a.streams), "--model", a.model, "--reps", str(a.reps),
                             "--instr", str(int(instr))], env=e, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]

@@ -114,7 +114,8 @@ def main():
         npz = os.path.join(td, "want.npz")
         np.savez(npz, base=base, out=want["out"], gains=want["gains"], vad=want["vad"])
         for v in variants:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", v, npz], env=dict(os.environ, RNNOISE_AMD_GRU_VARIANT=v),
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", v, npz], # (every form but w4 / w8 lives in the instrumented library only: the whole table is measured on that one)
+                               env=dict(os.environ, RNNOISE_AMD_GRU_VARIANT=v, RNNOISE_AMD_LIB=os.path.join(ROOT, "rnnoise_amd", "librnnoise_amd_instr.so")),
                                capture_output=True, text=True, timeout=600)
             out = [ln for ln in r.stdout.splitlines() if ln.startswith(v)]
             print(out[-1] if out else f"{v:8s} FAILED rc={r.returncode}: {(r.stderr or r.stdout)[-600:]}", flush=True)

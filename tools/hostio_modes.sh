@@ -4,6 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-r4f}
 O=$R/gpurun_out/$T
+export RNNOISE_AMD_LIB=$R/rnnoise_amd/librnnoise_amd_instr.so  # (the A/B switches below exist in the instrumented library only)
 mkdir -p "$O"; export TMPDIR=/tmp
 cd /tmp
 run() {  # tag, env..., -- bench args

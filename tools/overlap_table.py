@@ -30,7 +30,8 @@ CONFIGS = [
 
 def bench(env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-parity", "--steps", "40", "--warmup", "8", "--repeats", "9"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+                       # (RNNOISE_AMD_K1_LDS and the lab forms of the layer kernel exist in the instrumented library only: every row is measured on it)
+                       env=dict(os.environ, RNNOISE_AMD_LIB=os.path.join(ROOT, "rnnoise_amd", "librnnoise_amd_instr.so"), **env), capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     return json.loads(lines[-1]) if lines else None
 

@@ -5,6 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-sched}
+export RNNOISE_AMD_LIB=$R/rnnoise_amd/librnnoise_amd_instr.so  # (the A/B switches below exist in the instrumented library only)
 mkdir -p "$O"; export TMPDIR=/tmp; cd /tmp
 run() { local tag=$1; shift
   env "$@" python "$R/bench.py" --no-cpu-baseline --no-parity --repeats 11 ${EXTRA:-} 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', '${EXTRA:-}', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" | tee -a "$O/sweep.txt"; }
