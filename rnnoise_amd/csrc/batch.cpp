@@ -355,6 +355,60 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
     }
     return 0;
   };
+#if RN_INSTRUMENT
+  // LAB ($RNNOISE_AMD_FUSE_K3K1=1, instrumented library; profiles/r6_fused_k3k1.txt): synthesis(f - 1) as the prologue of analysis(f) in ONE
+  // kernel on the main stream -- [K3(f-1) . K1(f)] -> K2(f) -> [K3(f) . K1(f+1)] -> ... -- the high-pass ahead on its side stream, started
+  // behind the network of frame f - 3, and one trailing stand-alone synthesis at the end of the call
+  static const bool fuse_env = [] { const char *e = RN_LAB_ENV("FUSE_K3K1"); return e && atoi(e) == 1; }();
+  if (fuse_env && n_frames > 1 && !hk && pipe_force != 9 && b->n >= 6144) {
+    const bool whole = b->g.n_streams == b->g.n_stride && (size_t)b->g.n_streams * RN_GRU * 4 < (1ull << 32);
+    if (!(whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams())))) return -1;  // (layer-wise network only)
+    for (int f = 0; f < 3 && f < n_frames; f++)
+      if (highpass(f)) return -1;
+    for (int f = 0; f < n_frames; f++) {
+      RnGroupDev g = frame_group(f), gs = frame_group(f > 0 ? f - 1 : 0);
+      const int cur = (b->parity + f) % RN_SPEC_SLOTS, prev = (cur + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS, pprev = (prev + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
+      HIP_OK(hipStreamWaitEvent(st, b->cur_hp[f & 7], 0));
+      {
+        TimedLaunch t(b, 0);
+        b->cur_k1[f & 7] = t.on ? t.stop() : b->own_k1[f & 7];
+        HIP_OK(rn_launch_analysis_synth(&g, &gs, &b->tb, (b->ring_slot + f) % RN_RING_SLOTS, cur, d_out + buf(f > 0 ? f - 1 : 0) * N * RN_FRAME_SIZE * esz, s16,
+                                        f > 0 ? prev : -1, pprev, st, t.start(), b->cur_k1[f & 7]));
+      }
+      {
+        if (!b->img_valid) HIP_OK(rn_launch_nn_requant(&g, st));
+        b->img_valid = true;
+        std::unique_ptr<TimedLaunch> tl[5];
+        hipEvent_t ev[5][2] = {};
+        const int nl = rn_nn_layers_launches();
+        for (int i = 0; i < nl; i++) {
+          tl[i].reset(new TimedLaunch(b, 1));
+          ev[i][0] = tl[i]->start();
+          ev[i][1] = tl[i]->stop();
+        }
+        if (!ev[nl - 1][1]) ev[nl - 1][1] = b->own_k3[f & 7];
+        b->cur_k3[f & 7] = ev[nl - 1][1];  // (here: "the network of frame f is done" -- what the high-pass three frames ahead starts behind)
+        HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, ev));
+      }
+      if (f + 3 < n_frames) {
+        HIP_OK(hipStreamWaitEvent(sc, b->cur_k3[f & 7], 0));  // (beside the fused kernel of frame f + 1, not beside this frame's layer kernels)
+        if (highpass(f + 3)) return -1;
+      }
+      b->launches += b->timing ? 1 : 0;
+    }
+    {
+      const int f = n_frames - 1;
+      RnGroupDev g = frame_group(f);
+      const int cur = (b->parity + f) % RN_SPEC_SLOTS, prev = (cur + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS;
+      TimedLaunch t(b, 2);
+      HIP_OK(rn_launch_synthesis(&g, &b->tb, d_out + buf(f) * N * RN_FRAME_SIZE * esz, s16, cur, prev, st, t.start(), t.stop()));
+    }
+    b->parity = (b->parity + n_frames) % RN_SPEC_SLOTS;
+    b->ring_slot = (b->ring_slot + n_frames) % RN_RING_SLOTS;
+    b->frame_no += n_frames;
+    return 0;
+  }
+#endif
   if (pipelined) {
     for (int f = 0; f < 3 && f < n_frames; f++)
       if (highpass(f)) return -1;
@@ -377,10 +431,14 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
       if (whole && (b->nn_path == 2 || (b->nn_path == 1 && b->n >= nn_layers_min_streams()))) {
         if (!b->img_valid) HIP_OK(rn_launch_nn_requant(&g, st));
         b->img_valid = true;
-        // five launches, each timed on its own (kind 1: the durations add up to the network's)
-        TimedLaunch t0(b, 1), t1(b, 1), t2(b, 1), t3(b, 1), t4(b, 1);
-        hipEvent_t ev[5][2] = {{t0.start(), t0.stop()}, {t1.start(), t1.stop()}, {t2.start(), t2.stop()}, {t3.start(), t3.stop()},
-                               {t4.start(), t4.stop()}};
+        // four or five launches, each timed on its own (kind 1: the durations add up to the network's)
+        std::unique_ptr<TimedLaunch> tl[5];
+        hipEvent_t ev[5][2] = {};
+        for (int i = 0, nl = rn_nn_layers_launches(); i < nl; i++) {
+          tl[i].reset(new TimedLaunch(b, 1));
+          ev[i][0] = tl[i]->start();
+          ev[i][1] = tl[i]->stop();
+        }
         HIP_OK(rn_launch_nn_layers(&g, &b->m, &b->tb, st, ev));
       } else {
         TimedLaunch t(b, 1);

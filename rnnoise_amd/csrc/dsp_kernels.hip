@@ -1641,9 +1641,15 @@ static_assert(sizeof(SynthLds) <= 5120 && RN_WINDOW_SIZE <= 1052 && RN_BAND_QSTR
 #endif
 // LATE: the overlap-add operands behind the transform (the throughput form); !LATE: with everything else at the top (a handful of
 // waves on an empty machine have nobody to cover the extra round trip: rn_synthesis_few_kernel)
+// where a synthesis wave works: its stream, its lane number, its 4.9 KB of LDS (a one-wave workgroup of its own -- or, lab build, a wave
+// of a fused analysis workgroup: rn_analysis_synth_kernel)
+struct SynthPlace {
+  int s, lane;
+  char *lds;
+};
 template <bool LATE>
 __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTablesDev &tb, float *__restrict__ out, int parity_arg, int prev_arg,
-                                               const RnRows &rows) {
+                                               const RnRows &rows, const SynthPlace *place = nullptr) {
   // bit 8 of parity_arg: `out` holds int16 samples, written with the truncating conversion of the reference's only caller
   // (examples/rnnoise_demo.c:58: tmp[i] = x[i], float -> short as x86 compiles it: cvttss2si to 32 bits -- "integer
   // indefinite" 0x80000000 when out of range or NaN -- then the low 16 bits)
@@ -1653,8 +1659,8 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
   const int prev = listed ? (parity + RN_SPEC_SLOTS - 1) % RN_SPEC_SLOTS : prev_arg;
   const bool out_s16 = !listed && (parity_arg & 256);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  SynthLds &L = *reinterpret_cast<SynthLds *>(smem_raw);
-  const int s = listed ? RN_ROW_OF(re) : (int)blockIdx.x, lane = threadIdx.x, pos = fft_pos(lane);
+  SynthLds &L = *reinterpret_cast<SynthLds *>(place ? place->lds : smem_raw);
+  const int s = place ? place->s : (listed ? RN_ROW_OF(re) : (int)blockIdx.x), lane = place ? place->lane : (int)threadIdx.x, pos = fft_pos(lane);
   const float2 *dX = reinterpret_cast<const float2 *>(g.spec_X[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float2 *dP = reinterpret_cast<const float2 *>(g.spec_P[prev] + (size_t)s * RN_SPEC_STRIDE);
   const float *dE = g.spec_E[prev] + (size_t)s * 96;
@@ -1835,6 +1841,36 @@ extern "C" __global__ void __launch_bounds__(WAVE)
 rn_synthesis_few_kernel(RnGroupDev g, RnTablesDev tb, float *__restrict__ out, int parity_arg, int prev_arg, RnRows rows) {
   synthesis_body<false>(g, tb, out, parity_arg, prev_arg, rows);
 }
+
+#if RN_INSTRUMENT
+// ---- LAB (instrumented build only; VERDICT r5 Next #2, profiles/r6_fused_k3k1.txt) ----
+// Synthesis of frame t-1 as the PROLOGUE of the analysis of frame t: same wave = same stream, in the wave's own arena (4.9 of its 9.3 KB),
+// at the analysis kernel's occupancy.  The question: does the stage with the most HBM traffic per instruction hide under the
+// issue-bound one when they are phases of ONE kernel (waves of a CU drift apart between the six barriers of a workgroup), where as
+// separate kernels they cannot co-reside (profiles/r5_overlap.txt)?  gs: the group as frame t-1 sees it (its features / silence /
+// gains buffers); synth_cur < 0: no synthesis (first frame of a call).
+extern "C" __global__ void __launch_bounds__(WAVE * K1_SPW) __attribute__((amdgpu_waves_per_eu(4, 4)))
+rn_analysis_synth_kernel(RnGroupDev g, RnGroupDev gs, RnTablesDev tb, int slot, int parity, float *__restrict__ out, int synth_cur, int synth_prev) {
+  if (slot & 256) __builtin_amdgcn_s_setprio(1);
+  {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), s = (int)blockIdx.x * K1_SPW + wave;
+    if (synth_cur >= 0 && s < gs.n_streams) {
+      const SynthPlace pl{s, (int)(threadIdx.x & (WAVE - 1)), smem_raw + wave * sizeof(AnalysisLds)};
+      synthesis_body<true>(gs, tb, out, synth_cur, synth_prev, RnRows{}, &pl);
+      RN_WSYNC();
+    }
+  }
+  analysis_body<false, K1_SPW>(g, tb, slot & ~256, parity, RnTrainArgs{});
+}
+extern "C" hipError_t rn_launch_analysis_synth(const RnGroupDev *g, const RnGroupDev *gs, const RnTablesDev *tb, int slot, int parity, void *out,
+                                               int out_s16, int synth_cur, int synth_prev, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  const dim3 grid((g->n_streams + K1_SPW - 1) / K1_SPW), block(WAVE * K1_SPW);
+  RN_LAUNCH(rn_analysis_synth_kernel, grid, block, K1_SPW * sizeof(AnalysisLds), st, e0, e1, *g, *gs, *tb, slot | 256, parity,
+            static_cast<float *>(out), synth_cur < 0 ? -1 : (synth_cur | (out_s16 ? 256 : 0)), synth_prev);
+  return hipGetLastError();
+}
+#endif
 
 // host-visible launch helpers -----------------------------------------------------------------
 // (K0 lives in hp_kernel.hip; K0 and K1 are launched separately so that the host may put K0 of the next frame on a side stream)

@@ -711,27 +711,36 @@ rn_nn_gru_w4_altact_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer
   gru_body<2, 4, 1, false, true, !RN_GRU_PACKED_ACT>(g, m, tb, layer);
 }
 
+// round 6 (profiles/r6_dense_fold.txt): eight waves, one row buffer per wave, AND the output chains (dense_out, vad_dense) advanced
+// inside the layer launch as the units are produced (nn_gru.h: gru_body FOLD; the front kernel starts them: rn_nn_front_fold_kernel,
+// nn_mfma.hip) -- four launches instead of five, no 6 KB-per-stream re-read of the f32 state.  Bit-exact, and slower than the
+// five-launch network it was meant to replace.
+extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_fold_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb, int layer) {
+  gru_body<2, 8, 1, false, true, RN_GRU_PACKED_ACT, true>(g, m, tb, layer);
+}
+
 extern "C" const RnGruVariant *rn_gru_lab_variant(const char *name) {
   static const RnGruVariant variants[] = {
-      {"w4b2", rn_nn_gru_w4b2_kernel, 256, sizeof(GruLdsT<4, 2>), false},   {"w8b1", rn_nn_gru_w8b1_kernel, 512, sizeof(GruLdsT<8, 1>), false},
-      {"w4nodma", rn_nn_gru_w4nodma_kernel, 256, sizeof(GruLdsT<4, 1>), false},  // no LDS-DMA: pieces through registers
-      {"w4big", rn_nn_gru_kernel, 256, sizeof(GruLdsT<8, 3>), false},  // the product's w4 kernel asking for a whole CU's LDS: one workgroup per CU
-      {RN_GRU_PACKED_ACT ? "w4sc" : "w4pk", rn_nn_gru_w4_altact_kernel, 256, sizeof(GruLdsT<4, 1>), false},
+      {"w8f", rn_nn_gru_fold_kernel, 512, sizeof(GruLdsT<8, 1, true>), false, true},
+      {"w4b2", rn_nn_gru_w4b2_kernel, 256, sizeof(GruLdsT<4, 2>), false, false},   {"w8b1", rn_nn_gru_w8b1_kernel, 512, sizeof(GruLdsT<8, 1>), false, false},
+      {"w4nodma", rn_nn_gru_w4nodma_kernel, 256, sizeof(GruLdsT<4, 1>), false, false},  // no LDS-DMA: pieces through registers
+      {"w4big", rn_nn_gru_kernel, 256, sizeof(GruLdsT<8, 3>), false, false},  // the product's w4 kernel asking for a whole CU's LDS: one workgroup per CU
+      {RN_GRU_PACKED_ACT ? "w4sc" : "w4pk", rn_nn_gru_w4_altact_kernel, 256, sizeof(GruLdsT<4, 1>), false, false},
       // round 5 (gru_body2): o0 = the restructured body with nothing switched on, then one change at a time, then together
-      {"o0", rn_nn_gru2_o0_kernel, 512, sizeof(GruLds2T<1>), false},        {"bd", rn_nn_gru2_bd_kernel, 512, sizeof(GruLds2T<1>), false},
-      {"deep", rn_nn_gru2_deep_kernel, 512, sizeof(GruLds2T<1>), false},    {"ax", rn_nn_gru2_ax_kernel, 512, sizeof(GruLds2T<1>), false},
-      {"bdx", rn_nn_gru2_bdx_kernel, 512, sizeof(GruLds2T<1>), false},      {"p", rn_nn_gru2_p_kernel, 512, sizeof(GruLds2T<2>), true},
-      {"pbd", rn_nn_gru2_pbd_kernel, 512, sizeof(GruLds2T<2>), true},       {"pall", rn_nn_gru2_pall_kernel, 512, sizeof(GruLds2T<2>), true},
-      {"pbdx", rn_nn_gru2_pbdx_kernel, 512, sizeof(GruLds2T<2>), true},
+      {"o0", rn_nn_gru2_o0_kernel, 512, sizeof(GruLds2T<1>), false, false},        {"bd", rn_nn_gru2_bd_kernel, 512, sizeof(GruLds2T<1>), false, false},
+      {"deep", rn_nn_gru2_deep_kernel, 512, sizeof(GruLds2T<1>), false, false},    {"ax", rn_nn_gru2_ax_kernel, 512, sizeof(GruLds2T<1>), false, false},
+      {"bdx", rn_nn_gru2_bdx_kernel, 512, sizeof(GruLds2T<1>), false, false},      {"p", rn_nn_gru2_p_kernel, 512, sizeof(GruLds2T<2>), true, false},
+      {"pbd", rn_nn_gru2_pbd_kernel, 512, sizeof(GruLds2T<2>), true, false},       {"pall", rn_nn_gru2_pall_kernel, 512, sizeof(GruLds2T<2>), true, false},
+      {"pbdx", rn_nn_gru2_pbdx_kernel, 512, sizeof(GruLds2T<2>), true, false},
       // ... second step (gru_body3): twelve waves, the unit tile's register block split by gates
-      {"v3", rn_nn_gru3_kernel, 768, sizeof(GruLds3T<2>), true},            {"v3nobd", rn_nn_gru3_nobd_kernel, 768, sizeof(GruLds3T<2>), true},
-      {"v3np", rn_nn_gru3_np_kernel, 768, sizeof(GruLds3T<1>), false},      {"v3mprio", rn_nn_gru3_mprio_kernel, 768, sizeof(GruLds3T<2>), true},
+      {"v3", rn_nn_gru3_kernel, 768, sizeof(GruLds3T<2>), true, false},            {"v3nobd", rn_nn_gru3_nobd_kernel, 768, sizeof(GruLds3T<2>), true, false},
+      {"v3np", rn_nn_gru3_np_kernel, 768, sizeof(GruLds3T<1>), false, false},      {"v3mprio", rn_nn_gru3_mprio_kernel, 768, sizeof(GruLds3T<2>), true, false},
       // timing experiments, WRONG RESULTS (what a part costs = what leaving it out saves):
-      {"v3nomfma", rn_nn_gru3_nomfma_kernel, 768, sizeof(GruLds3T<2>), true}, {"v3noact", rn_nn_gru3_noact_kernel, 768, sizeof(GruLds3T<2>), true},
-      {"v3neither", rn_nn_gru3_neither_kernel, 768, sizeof(GruLds3T<2>), true},
-      {"v3hita", rn_nn_gru3_hita_kernel, 768, sizeof(GruLds3T<2>), true},   {"v3hitaneither", rn_nn_gru3_hita_neither_kernel, 768, sizeof(GruLds3T<2>), true},
-      {"w4chk", rn_nn_gru_w4_chk_kernel, 256, sizeof(GruLdsT<4, 1>), false}, {"w8b1chk", rn_nn_gru_w8b1_chk_kernel, 512, sizeof(GruLdsT<8, 1>), false},
-      {"w8chk", rn_nn_gru_chk_kernel, 512, sizeof(GruLdsT<8, 3>), false},
+      {"v3nomfma", rn_nn_gru3_nomfma_kernel, 768, sizeof(GruLds3T<2>), true, false}, {"v3noact", rn_nn_gru3_noact_kernel, 768, sizeof(GruLds3T<2>), true, false},
+      {"v3neither", rn_nn_gru3_neither_kernel, 768, sizeof(GruLds3T<2>), true, false},
+      {"v3hita", rn_nn_gru3_hita_kernel, 768, sizeof(GruLds3T<2>), true, false},   {"v3hitaneither", rn_nn_gru3_hita_neither_kernel, 768, sizeof(GruLds3T<2>), true, false},
+      {"w4chk", rn_nn_gru_w4_chk_kernel, 256, sizeof(GruLdsT<4, 1>), false, false}, {"w8b1chk", rn_nn_gru_w8b1_chk_kernel, 512, sizeof(GruLdsT<8, 1>), false, false},
+      {"w8chk", rn_nn_gru_chk_kernel, 512, sizeof(GruLdsT<8, 3>), false, false},
   };
   for (const RnGruVariant &v : variants)
     if (!strcmp(name, v.name)) return &v;

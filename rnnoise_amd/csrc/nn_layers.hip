@@ -28,6 +28,30 @@ extern "C" __global__ void __launch_bounds__(512) rn_nn_gru_w8_kernel(RnGroupDev
 extern "C" const RnGruVariant *rn_gru_lab_variant(const char *name);  // lab/nn_gru_lab.hip: the A/B forms of the instrumented build
 #endif
 
+static const RnGruVariant gru_product[2] = {{"w4", rn_nn_gru_kernel, 256, sizeof(GruLdsT<4, 1>), false, false},
+                                             {"w8", rn_nn_gru_w8_kernel, 512, sizeof(GruLdsT<8, 3>), false, false}};
+static const RnGruVariant *gru_forced_variant() {
+  static const RnGruVariant *const forced = []() -> const RnGruVariant * {
+
+    const char *e = getenv("RNNOISE_AMD_GRU_VARIANT");
+    if (!e || !*e) return nullptr;
+    for (const RnGruVariant &v : gru_product)
+      if (!strcmp(e, v.name)) return &v;
+#if RN_INSTRUMENT
+    if (const RnGruVariant *v = rn_gru_lab_variant(e)) return v;
+#endif
+    fprintf(stderr, "[rnnoise_amd] RNNOISE_AMD_GRU_VARIANT=%s: no such form of the layer kernel in this build (w4 | w8)\n", e);
+    static const RnGruVariant none = {nullptr, nullptr, 0, 0, false, false};
+    return &none;
+  }();
+  return forced;
+}
+// does the layer-wise network of this process fold the output chains into its layer launches?  (nn_mfma.hip: rn_launch_nn_layers)
+extern "C" int rn_nn_layers_fold(void) {
+  const RnGruVariant *f = gru_forced_variant();
+  return f && f->k && f->fold;
+}
+
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,
                                              hipEvent_t e0, hipEvent_t e1) {
   const int n_tiles = (g->n_streams + TS - 1) / TS, n_groups = (n_tiles + GM - 1) / GM;
@@ -36,20 +60,7 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
   // form while every group has a CU to itself (a four-wave workgroup would then leave each SIMD with ONE wave: 16,384 streams 0.200
   // against 0.174 ms for the three layers + front + dense).  $RNNOISE_AMD_GRU_VARIANT = w4 | w8 forces one (tests run both at every
   // size); any other name is an error, not a silent default -- the instrumented build knows more names (lab/nn_gru_lab.hip).
-  static const RnGruVariant product[2] = {{"w4", rn_nn_gru_kernel, 256, sizeof(GruLdsT<4, 1>), false},
-                                          {"w8", rn_nn_gru_w8_kernel, 512, sizeof(GruLdsT<8, 3>), false}};
-  static const RnGruVariant *const forced = []() -> const RnGruVariant * {
-    const char *e = getenv("RNNOISE_AMD_GRU_VARIANT");
-    if (!e || !*e) return nullptr;
-    for (const RnGruVariant &v : product)
-      if (!strcmp(e, v.name)) return &v;
-#if RN_INSTRUMENT
-    if (const RnGruVariant *v = rn_gru_lab_variant(e)) return v;
-#endif
-    fprintf(stderr, "[rnnoise_amd] RNNOISE_AMD_GRU_VARIANT=%s: no such form of the layer kernel in this build (w4 | w8)\n", e);
-    static const RnGruVariant none = {nullptr, nullptr, 0, 0, false};
-    return &none;
-  }();
+  static const RnGruVariant *const forced = gru_forced_variant();
   if (forced && !forced->k) return hipErrorInvalidValue;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -60,7 +71,7 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     cus[dev].store(ncu, std::memory_order_relaxed);
   }
-  const RnGruVariant &v = forced ? *forced : product[n_groups > ncu ? 0 : 1];
+  const RnGruVariant &v = forced ? *forced : gru_product[n_groups > ncu ? 0 : 1];
   // more than 64 KB of LDS is an opt-in, per kernel and device (a process may hold batches on several GPUs)
   if (hipError_t e = rn_gru_opt_in(v, dev)) return e;
   int grid = n_groups, flags = 0;

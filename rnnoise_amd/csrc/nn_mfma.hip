@@ -41,6 +41,17 @@ struct FrontLds {
   int8_t xq[2][KT * 64 * 16];
 };
 
+// ... and with the output chains' staging (RN_NN_MODE 2): the f32 conv2 outputs of the tile, 24 KB, over the conv1 input (dead behind
+// conv1's barrier): 44 KB -- three workgroups per CU, which is what the kernel's registers allow anyway
+struct FrontFoldLds {
+  uint16_t lut[4096];
+  union {
+    float tmp1[TS][197];
+    float stage[RN_GRU / 4][TS][4];
+  };
+  int8_t xq[2][KT * 64 * 16];
+};
+
 // one int8 output-row tile: 6 MFMAs over K=384, A straight from the pre-swizzled weights
 // (B fragments are re-read from LDS per use -- conflict-free 16-byte reads -- rather than held in 48 VGPRs)
 __device__ __forceinline__ v4i int8_tile(const int8_t *__restrict__ wmf, int rt, int lane, const int8_t *bq) {
@@ -70,6 +81,12 @@ extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_front_kernel(RnGrou
 #undef RN_NN_MODE
 }
 #if RN_INSTRUMENT
+// LAB (profiles/r6_dense_fold.txt): the front with the output chains taken through the conv2 segment (nn_gru.h: gru_body FOLD)
+extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_front_fold_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
+#define RN_NN_MODE 2
+#include "nn_tile_body.inc"
+#undef RN_NN_MODE
+}
 // the same at <= 64 VGPRs (A/B of the instrumented build, $RNNOISE_AMD_FRONT64=1): the front's 33 KB of LDS allow four workgroups per
 // CU, its 66 -> 72 allocated registers x 2 waves per SIMD only three
 extern "C" __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -89,16 +106,21 @@ extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelD
                                              hipEvent_t e0, hipEvent_t e1);
 extern "C" hipError_t rn_launch_nn_dense(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st, hipEvent_t e0,
                                          hipEvent_t e1);
-// the same network as five launches (front, three GRU layers at 64 streams per workgroup, dense); ev[i] = the optional
-// (start, stop) events of launch i: each kernel is timed on its own, the five durations add up to the network's
+extern "C" int rn_nn_layers_fold(void);  // nn_layers.hip
+// launches of the layer-wise network: front, three GRU layers, dense -- or, with the output chains folded into the layer launches, four
+extern "C" int rn_nn_layers_launches(void) { return rn_nn_layers_fold() ? 4 : 5; }
+// the network layer by layer (front, three GRU layers at 64 streams per workgroup, [dense]); ev[i] = the optional (start, stop) events
+// of launch i: each kernel is timed on its own, the durations add up to the network's
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
                                           hipEvent_t ev[5][2]) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm || !g->act_q[0] || g->n_streams != g->n_stride) return hipErrorNotSupported;
   if ((size_t)g->n_streams * RN_GRU * 4 >= (1ull << 32)) return hipErrorNotSupported;  // 32-bit offsets in nn_layers.hip
   const dim3 grid((g->n_streams + TS - 1) / TS);
+  const bool fold = rn_nn_layers_fold();
 #if RN_INSTRUMENT
   static const bool front64 = [] { const char *e = RN_LAB_ENV("FRONT64"); return e && atoi(e) == 1; }();
-  if (front64) RN_LAUNCH(rn_nn_front64_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
+  if (fold) RN_LAUNCH(rn_nn_front_fold_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
+  else if (front64) RN_LAUNCH(rn_nn_front64_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
   else
 #endif
     RN_LAUNCH(rn_nn_front_kernel, grid, dim3(NTHREADS), 0, st, ev[0][0], ev[0][1], *g, *m, *tb);
@@ -106,6 +128,6 @@ extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *g, const RnModelDev 
     hipError_t e = rn_launch_nn_gru_layer(g, m, tb, k, st, ev[1 + k][0], ev[1 + k][1]);
     if (e != hipSuccess) return e;
   }
-  return rn_launch_nn_dense(g, m, tb, st, ev[4][0], ev[4][1]);
+  return fold ? hipGetLastError() : rn_launch_nn_dense(g, m, tb, st, ev[4][0], ev[4][1]);
 }
 extern "C" int rn_nn_mfma_available(void) { return 1; }

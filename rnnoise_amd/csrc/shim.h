@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -44,10 +45,13 @@ extern "C" hipError_t rn_launch_nn_one(const RnGroupDev *, const RnModelDev *, c
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
                                         hipEvent_t);
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
+extern "C" int rn_nn_layers_launches(void);
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);
 extern "C" int rn_nn_mfma_available(void);
 extern "C" hipError_t rn_launch_release_store(void *, long long, hipStream_t);
 #if RN_INSTRUMENT
+extern "C" hipError_t rn_launch_analysis_synth(const RnGroupDev *, const RnGroupDev *, const RnTablesDev *, int, int, void *, int, int, int, hipStream_t,
+                                               hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_log_energy(const float *, unsigned, float *, unsigned, const double *, hipStream_t);
 extern "C" hipError_t rn_launch_fft_probe(int, const float *, float *, unsigned long long *, int, int, const RnTablesDev *, hipStream_t);
 extern "C" hipError_t rn_launch_xlane_probe(int *, hipStream_t);

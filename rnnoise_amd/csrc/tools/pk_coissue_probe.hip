@@ -25,11 +25,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-enum Victim { V_SCALAR, V_PK_PLAIN, V_PK_SELHI, V_PK_SEL, V_PK_FMA, V_PK_MOV, V_F64, V_PK_SEL0, V_PK_ADDSEL, V_PK_FMASEL, V_PK_SWAP, NV };
+enum Victim { V_SCALAR, V_PK_PLAIN, V_PK_SELHI, V_PK_SEL, V_PK_FMA, V_PK_MOV, V_F64, V_PK_SEL0, V_PK_ADDSEL, V_PK_FMASEL, V_PK_SWAP,
+              V_PK_SELHI0, V_PK_FMA_SELHI2, V_PK_FMA_SELHI12, V_PK_FMA_SEL2, V_PK_ADD_SELHI_NEG, NV };
 static const char *VN[] = {"v_mul_f32 + v_add_f32 (control)", "v_pk_mul_f32 + v_pk_add_f32", "v_pk_mul_f32 op_sel_hi:[1,0] + v_pk_add_f32",
                            "v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32", "v_pk_fma_f32", "v_pk_mov_b32 op_sel:[1,0] + v_pk_add_f32", "v_fma_f64",
                            "v_pk_mul_f32 op_sel:[1,0] + v_pk_add_f32", "v_pk_mul_f32 + v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
-                           "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] + v_pk_add_f32"};
+                           "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] + v_pk_add_f32",
+                           // round 6: the remaining operand selects the library's kernels contain (op_sel_hi on src0 / src2, with VGPR-pair operands)
+                           "v_pk_mul_f32 op_sel_hi:[0,1] + v_pk_add_f32", "v_pk_fma_f32 op_sel_hi:[1,1,0]", "v_pk_fma_f32 op_sel_hi:[1,0,0]",
+                           "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mul_f32 + v_pk_add_f32 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]"};
 enum Aggressor { A_IDLE, A_MFMA_I8, A_MFMA_F32, A_VALU, A_PK, A_F64, A_LDS, A_MFMA_I8_CHAIN, A_MFMA_I8_BURST, A_MFMA_F32_IND, A_MFMA_BF16, A_MFMA_I8_32, NA };
 static const char *AN[] = {"idle (s_sleep)", "v_mfma_i32_16x16x64_i8 x12 independent", "v_mfma_f32_16x16x4_f32 chain", "v_fma_f32 flood", "v_pk_fma_f32 flood",
                            "v_fma_f64 flood", "ds_read_b128 flood", "v_mfma_i32_16x16x64_i8 dependent chain", "6 x v_mfma_i32_16x16x64_i8, then ~200 clocks of VALU",
@@ -97,6 +101,23 @@ __device__ __forceinline__ v2f victim_chain(int iters, unsigned seed, int stagge
       x = v2f{.5f * x0, x0};
       asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(w), "v"(x));
       asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_SELHI0) {  // both halves of src0 from its low dword (the form of the analysis kernel's coarse chains)
+      x.y = x0;
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    } else if (FORM == V_PK_FMA_SELHI2) {  // the addend's high half from its low dword (the layer kernel's Horner steps with a broadcast constant)
+      x.y = x0;
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w), "v"(x));
+    } else if (FORM == V_PK_FMA_SELHI12) {
+      x.y = x0;
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(w), "v"(x));
+    } else if (FORM == V_PK_FMA_SEL2) {  // an op_sel bit on the THIRD source
+      x.y = x0;
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1]" : "+v"(acc) : "v"(w), "v"(x));
+    } else if (FORM == V_PK_ADD_SELHI_NEG) {  // (1 - z) of the layer kernel's blend: v_pk_add_f32 with a broadcast, negated operand
+      x.y = x0;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(w), "v"(x));
+      asm volatile("v_pk_add_f32 %0, %1, %0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "+v"(acc) : "v"(p));
     } else {  // V_F64
       const double xd = (double)x0, wd = (double)w.x;
       asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(dacc) : "v"(wd), "v"(xd));
@@ -123,6 +144,11 @@ __device__ __forceinline__ v2f victim_run(int form, int iters, unsigned seed, in
     case V_PK_ADDSEL: return victim_chain<V_PK_ADDSEL>(iters, seed, stagger);
     case V_PK_FMASEL: return victim_chain<V_PK_FMASEL>(iters, seed, stagger);
     case V_PK_SWAP: return victim_chain<V_PK_SWAP>(iters, seed, stagger);
+    case V_PK_SELHI0: return victim_chain<V_PK_SELHI0>(iters, seed, stagger);
+    case V_PK_FMA_SELHI2: return victim_chain<V_PK_FMA_SELHI2>(iters, seed, stagger);
+    case V_PK_FMA_SELHI12: return victim_chain<V_PK_FMA_SELHI12>(iters, seed, stagger);
+    case V_PK_FMA_SEL2: return victim_chain<V_PK_FMA_SEL2>(iters, seed, stagger);
+    case V_PK_ADD_SELHI_NEG: return victim_chain<V_PK_ADD_SELHI_NEG>(iters, seed, stagger);
     default: return victim_chain<V_F64>(iters, seed, stagger);
   }
 }
@@ -266,13 +292,14 @@ extern "C" __global__ void __launch_bounds__(64) probe_victim(int form, int v_it
 
 #define OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 int main(int argc, char **argv) {
-  int iters = 4000, two = 1, roles = 2, reps = 3, sweep = 0;
+  int iters = 4000, two = 1, roles = 2, reps = 3, sweep = 0, form0 = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--two")) two = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--roles")) roles = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--sweep")) sweep = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--from-form")) form0 = atoi(argv[i + 1]);
   }
   unsigned *d_out;
   float *d_sink;
@@ -290,7 +317,7 @@ int main(int argc, char **argv) {
            prop.gcnArchName, PROBE_BUILD, iters, two ? "two kernels (aggressor: 4-wave workgroups, 230 VGPRs, 72 KB LDS; victim: one-wave workgroups)" : "one kernel (8 waves, 2 per SIMD)", reps);
     printf("# line = victim form | aggressor | staggers that fired / staggers tried | wrong victim waves / waves checked | lanes by quarter | stagger:wrong-waves list\n");
     const int kinds[2] = {A_MFMA_I8, A_MFMA_BF16};
-    for (int form = 0; form < NV; form++) {
+    for (int form = form0; form < NV; form++) {
       for (int kk = 0; kk < 2; kk++) {
         const int kind = kinds[kk];
         unsigned long long tot[8] = {};

@@ -31,6 +31,10 @@ for n in (1, int(sys.argv[1]) if len(sys.argv) > 1 else 4096):
             print("    gru1, inside a unit tile (wave 0): input gates | conversion | recurrent gates | wait + rows + conversion | activations + stores")
             for ui in range(3):
                 print(f"    unit tile {ui}: " + " ".join(f"{u[:, 5 * ui + i].mean():9.0f}" for i in range(5)))
+            x = d[::64, 1391:1395]
+            if x.any():  # (the fold form of the layer kernel: the output chains' burst behind each unit tile, and the tail)
+                print("    output chains (wave 0): burst behind unit tile 0 | 1 | 2 | tail behind the last unit tile")
+                print("    " + " ".join(f"{x[:, i].mean():9.0f}" for i in range(4)))
     clk = d[:, 1348:1360]
     print(f"--- N={n}: mean shader clocks per section over streams (total {clk.sum(1).mean():.0f}) ---")
     for k, name in enumerate(NAMES):
