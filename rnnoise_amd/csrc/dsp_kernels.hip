@@ -848,6 +848,9 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   const bool xrow = !(RN_INSTRUMENT && (slot_arg & 1024));              // bit 10: the doubling dots read x per lane from LDS (chain_dot8_y2)
   const int narrow_prio = (RN_INSTRUMENT && (slot_arg & 4096)) ? 1 : 3; // bit 12: the narrow-phase waves keep the kernel's priority
   const bool fine_deep = !(RN_INSTRUMENT && (slot_arg & 16384));        // bit 14: the fine-search chains fetch one block ahead, not two
+  // bit 13: TIMING ONLY, WRONG RESULTS -- the 31 candidate chains of remove_doubling read at offsets 2 l (one bank pair per lane: no bank
+  // conflict is possible): what the kernel would take if the conflicts of that pass were gone (profiles/r6_k1_dots_conflicts.txt)
+  const bool dots_noconf = RN_INSTRUMENT && (slot_arg & 8192);
   const int nw0 = spread ? (int)((blockIdx.x * 0x9E3779B1u) >> 30) : 0;
   const int nw1 = nw0, nw2 = spread ? (nw0 + 1) & 3 : 0, nw3a = spread ? (nw0 + 2) & 3 : 0, nw3b = spread ? (nw0 + 3) & 3 : 0;
   const int ring0 = RN_RING0(slot);
@@ -1323,6 +1326,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         off = T0g + ((l & 1) ? 1 : -1);
         if (off < 0) off = 0;
       }
+      if (dots_noconf && off >= 0) off = 2 * l;
       // every lane runs a chain (chain_dot16_xrow takes x from the registers of the other lanes of its row); the lanes without
       // an offset of their own run <x, x>, all of them on the same addresses (a broadcast, not a bank conflict), and drop it
       const int a = maxperiod - (off >= 0 ? off : 0);  // y = x_lp + a
@@ -1891,7 +1895,7 @@ extern "C" hipError_t rn_launch_analysis(const RnGroupDev *g, const RnTablesDev 
     static const int stop = [] { const char *e = RN_LAB_ENV("K1_STOP"); return (RN_INSTRUMENT && e) ? atoi(e) << 16 : 0; }();
     static const int noxrow = [] {
       const char *e = RN_LAB_ENV("K1_XROW"), *x = RN_LAB_ENV("K1_EXPERIMENT");  // (A/B bits 12, 14: see analysis_body)
-      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (4096 | 16384)) : 0);
+      return ((e && atoi(e) == 0) ? 1024 : 0) | (x ? (atoi(x) & (4096 | 8192 | 16384)) : 0);
     }();
     RN_LAUNCH(rn_analysis_kernel, grid, block, K1_SPW * lds1, st, e0, e1, *g, *tb, slot | prio | stop | noxrow, parity);
   }

@@ -28,10 +28,16 @@ python "$R/tools/k1_cycles.py" 65536 --nn --layers 2>&1 | grep -v amdgpu.ids > "
 python "$R/tools/configs0.py" 2>&1 | grep configs > "$O/configs0.txt"
 # the drop-in call from plain C threads (the combiner of dropin.cpp): throughput, CPU time per frame, more states than threads, pool sizes
 bash "$R/tools/configs0_scope.sh" 2>&1 | grep -v amdgpu.ids > "$O/configs0_cthreads.txt"
-# round 5: the host-fed path's copy modes, the layer kernel's variants, what the frame pipeline hides
+# the host-fed path's copy modes (round 5) and what its step is made of (round 6)
 bash "$R/tools/hostio_sdma.sh" 2>&1 | grep -v amdgpu.ids > "$O/hostio_sdma.txt"
-python "$R/tools/gru_variants.py" w4 w8 p v3 2>&1 | grep -v amdgpu.ids > "$O/gru_variants.txt"
-python "$R/tools/overlap_table.py" 2>&1 | grep -v amdgpu.ids > "$O/overlap.txt"
+bash "$R/tools/hostio_breakdown.sh" 2>&1 | grep -v amdgpu.ids > "$O/hostio_breakdown.txt"
+# round 6: what rn_analysis_kernel would take without the bank conflicts of its candidate dots (instrumented library, timing only)
+bash "$R/tools/k1_dots_conflicts.sh" 2>&1 | grep -v amdgpu.ids > "$O/k1_dots_conflicts.txt"
+# round 5's investigations (the layer kernel's lab forms, what the frame pipeline hides): COLLECT_R5=1 repeats them on the instrumented library
+if [ "${COLLECT_R5:-0}" = 1 ]; then
+  python "$R/tools/gru_variants.py" w4 w8 p v3 2>&1 | grep -v amdgpu.ids > "$O/gru_variants.txt"
+  python "$R/tools/overlap_table.py" 2>&1 | grep -v amdgpu.ids > "$O/overlap.txt"
+fi
 python "$R/tools/fft_bench.py" 2>&1 | grep -v amdgpu.ids > "$O/fft_bench.txt"
 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python "$R/bench.py" --no-cpu-baseline --repeats 5 > "$O/trace.log" 2>&1
 python "$R/tools/prof_summary.py" "$(ls "$O"/trace/*/*_results.db | head -1)" \

@@ -21,7 +21,7 @@ for n in ("k1_sections.csv",):
     if os.path.exists(os.path.join(src, n)):
         shutil.copy(os.path.join(src, n), os.path.join(dst, f"{pre}_{n}"))
 for n in ("serial_times", "section_taps_65536", "configs0", "configs0_cthreads", "k1_sections", "k1_narrow", "fft_bench", "network_schedules_65536", "pcie_peak",
-          "valu_issue", "hostio_sdma", "gru_variants", "overlap"):
+          "valu_issue", "hostio_sdma", "hostio_breakdown", "k1_dots_conflicts", "gru_variants", "overlap"):
     if os.path.exists(os.path.join(src, n + ".txt")):
         shutil.copy(os.path.join(src, n + ".txt"), os.path.join(dst, f"{pre}_{n}.txt"))
 
