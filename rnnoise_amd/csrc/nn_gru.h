@@ -21,17 +21,17 @@
 // W: waves per GRU workgroup, HB: f32 row buffers per wave.  <4, 1>: one wave per SIMD and workgroup, 72 KB -- two workgroups per
 // CU, or one beside analysis workgroups of the next frame (batches with more 64-stream groups than CUs); <8, 3>: one buffer per
 // unit tile of a wave, every buffer written once per launch, 152 KB -- a workgroup owns its CU (smaller batches).
-// FOLD: dense_out / vad_dense advanced inside the layer kernel (gru_body: "the output chains").  Every wave leaves the f32 values of
-// the unit tile it has just produced in a staging block of its own, in the order the chains want them -- [input / 4][stream][input % 4]:
-// an MFMA B operand is word 4 n + gq of a 64-word row, a VAD lane's four inputs one 16-byte read -- two blocks per wave, so that a
-// wave two unit tiles ahead of the slowest chain still has somewhere to write.
+// FOLD (instrumented build only): dense_out / vad_dense advanced inside the layer kernel -- lab/nn_gru_fold.inc has the staging area
+// (GruFoldLds), the code (spliced into gru_body at five places below) and the record of why the product does not do it
+// (profiles/r6_dense_fold.txt).
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 0
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#else
 template <int W>
-struct GruFoldLds {
-  float stage[2][W][4][GM * TS][4];
-  float vadw[RN_GRU];  // vad_dense's weights of this layer's 384 inputs (the VAD lanes all read the same ones: a broadcast)
-  int ready[24];     // unit tile u is staged (set by its producer)
-  int consumed[24];  // chain-owner waves that are done with unit tile u (W / 2 of them; the VAD chains ride on the last one)
-};
+struct GruFoldLds {};  // (the product never instantiates FOLD)
+#endif
 struct GruNoFoldLds {};
 template <int W, int HB, bool FOLD = false>
 struct GruLdsT {
@@ -234,18 +234,11 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) {
 // The A fragments come from L2 (~600 cycles): a rolling buffer keeps them AD k-steps ahead of their MFMAs, across the
 // boundary between the input and the recurrent matrix (step = 0..5 input, 6..11 recurrent).
 // (AD is a template parameter of the kernel body; 3 and 4 k-steps ahead were measured too and change nothing: profiles/r4_gru_experiments.txt)
-// The flags of the output chains (GruFoldLds) are touched through these: as __atomic builtins the compiler put s_waitcnt vmcnt(0) in
-// front of each of them -- a wait for every state store of the unit tile to be acknowledged by HBM, thousands of cycles, per burst.
-// A wave's LDS instructions execute in issue order and these are volatile: that is all the ordering the protocol needs.
-typedef volatile __attribute__((address_space(3))) int *lds_flag_ptr;
-__device__ __forceinline__ int flag_load(const int *p) { return *(lds_flag_ptr)p; }
-__device__ __forceinline__ void flag_store(int *p, int v) { *(lds_flag_ptr)p = v; }
-__device__ __forceinline__ void flag_add1(int *p) {
-  const unsigned a = lds_addr(p);
-  const int one = 1;
-  asm volatile("ds_add_u32 %0, %1" ::"v"(a), "v"(one) : "memory");
-}
-
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 6
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#endif
 template <int AD>
 struct AFrags {
   v4i f[AD + 1][3];
@@ -361,13 +354,11 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
     for (int c = wave; c < 8; c += W)  // the LUT is 8 pieces
       piece(reinterpret_cast<const uint32_t *>(tb.rcp16) + c * 256 + lane * 4, L.lut, c * 1024);
     rows_fetch(0);
-    if constexpr (FOLD) {
-      if (tid < 24) {
-        L.fold.ready[tid] = 0;
-        L.fold.consumed[tid] = 0;
-      }
-      if (tid < RN_GRU / 4) *reinterpret_cast<v4f *>(&L.fold.vadw[4 * tid]) = ldg<v4f>(m.vad_dense.fw, (unsigned)(RN_GRU * (layer + 1) + 4 * tid) * 4u);
-    }
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 1
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   const unsigned long long clk1 = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
@@ -409,128 +400,11 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
   // other's epilogue.
   if (wave < W / 2 && !no_prio) __builtin_amdgcn_s_setprio(2);
   [[maybe_unused]] v4f h_prev[GM] = {};
-  // ---- the output chains (FOLD): dense_out (1536 -> 32) and vad_dense (1536 -> 1), src/rnn.c:53-58, advanced HERE ----
-  // Both layers are serial chains over cat = [conv2 out | gru1 | gru2 | gru3] (bit parity fixes the summation order): dense_out as
-  // dependent v_mfma_f32_16x16x4_f32 per (16-stream tile, 16-output row tile), vad_dense as unfused multiply-adds per stream
-  // (src/vec_avx.h:732-736).  Until round 5 a kernel of their own ran them after the third layer, re-reading all 6 KB of f32 state per
-  // stream from HBM -- 0.107 ms per step at 65,536 streams, bound by that read.  Now the 33 partial sums of a stream travel from launch
-  // to launch (in g.gains / g.vad: the front kernel has taken them through the conv2 segment) and this layer's 384 inputs are added
-  // where they are produced: every wave stages each finished unit tile in LDS (GruFoldLds) and raises a flag; the chains belong to the
-  // workgroup's OLDER waves -- the ones with issue priority, which run ahead of their SIMD partners and used to leave the kernel a
-  // quarter of its duration early: wave w < W / 2 owns both row tiles of stream tile w for the whole launch and takes the staged tiles in
-  // unit order, whoever produced them; the last of them also runs the 64 VAD chains, lane = stream.  No barrier, and the younger waves --
-  // the ones the workgroup's duration hangs on -- pay four LDS writes per unit tile.
-  constexpr int NOWN = W / 2;
-  const bool owner = wave < NOWN, vad_wave = wave == NOWN - 1;
-  [[maybe_unused]] v4f dacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // row tiles 0, 1 of stream tile `wave`
-  [[maybe_unused]] float vacc = 0.f;
-  [[maybe_unused]] int chain_u = 0;  // next unit tile of this wave's chains
-  // (recomputed where they are used -- the first and the last lines of the kernel -- from an opaque copy of the thread number, so that
-  //  they do not sit in registers, or in scratch, through everything in between)
-  struct ChainWhere {
-    int cs, csc, vs, vsc;  // the stream of this lane's accumulator column, and of its VAD chain; clamped copies for loads
-    unsigned acc_off;      // byte offset of the lane's four partial sums of row tile 0 in g.gains (row tile 1: + 64)
-  };
-  auto chain_where = [&]() {
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-    const int w_ = t_ >> 6, l_ = t_ & 63;
-    ChainWhere c;
-    c.cs = (tile0 + w_) * TS + (l_ & 15);
-    c.csc = c.cs < N ? c.cs : N - 1;
-    c.vs = tile0 * TS + l_;
-    c.vsc = c.vs < N ? c.vs : N - 1;
-    c.acc_off = (unsigned)(c.csc * RN_NB_BANDS + 4 * (l_ >> 4)) * 4u;
-    return c;
-  };
-  if constexpr (FOLD) {
-    if (owner) {
-      const ChainWhere c = chain_where();
-      dacc[0] = ldg<v4f>(g.gains, c.acc_off);
-      dacc[1] = ldg<v4f>(g.gains, c.acc_off + 64u);
-      if (vad_wave) vacc = g.vad[c.vsc];
-    }
-  }
-  // A wave's chains advance in BURSTS of up to W unit tiles (a round's worth), once per unit tile of its own: behind its stores, where the
-  // register file is nearly empty.  What a burst needs from L2 -- the dense_out weights of its tiles in MFMA operand order, one 16-byte
-  // load per tile, row tile and lane = the operands of that tile's four chain steps (model.cpp: stage_linear) -- is requested at the
-  // top of the burst, for exactly the tiles it will take, all at once, and arrives under the burst's LDS reads.  (Requested a stretch
-  // earlier the loads stayed "pending" in the compiler's book-keeping on the paths that take fewer tiles, and the next write to one of
-  // their registers -- in the NEXT unit tile's activations -- got an s_waitcnt vmcnt(0): a wait for the row DMA queued behind them,
-  // 3 k cycles per unit tile.  vmcnt retires in order: in this kernel every vector load has to be placed with the DMA pieces in mind.)
-  // takes the staged unit tiles chain_u .. chain_u + W - 1, in order, as far as they are there
-  auto chain_burst = [&]() {
-    if constexpr (FOLD) {
-      constexpr int BW = 2;  // unit tiles per pass (a pass holds 2 x BW weight vectors and BW x 4 B operands in registers)
-#pragma unroll 1
-      for (;;) {
-        const int a_base = chain_u;
-        int rdy[BW];
-#pragma unroll
-        for (int j = 0; j < BW; j++) rdy[j] = a_base + j < 24 ? flag_load(&L.fold.ready[a_base + j]) : 0;
-        int nr = 0;
-        bool open = true;
-#pragma unroll
-        for (int j = 0; j < BW; j++) {
-          open = open && __builtin_amdgcn_readfirstlane(rdy[j]);
-          if (open) nr = j + 1;
-        }
-        asm volatile("" ::: "memory");  // (the staged values are read AFTER the flags: a wave's LDS reads execute in issue order)
-        if (nr == 0) break;
-        v4f a_pre[BW][2];
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-          if (j < nr) {
-#pragma unroll
-            for (int rt = 0; rt < 2; rt++)
-              a_pre[j][rt] = ldg<v4f>(m.dense_out.fwm, (unsigned)(((rt * (RN_CAT / 16) + 24 * (layer + 1) + a_base + j) * 64 + lane) * 16));
-          }
-        float bx[BW][4];
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-          if (j < nr) {
-            const int u = a_base + j;
-            const float *S = &L.fold.stage[(u / W) & 1][u % W][0][0][0];
-#pragma unroll
-            for (int e = 0; e < 4; e++) bx[j][e] = S[(e * (GM * TS) + TS * wave + n) * 4 + gq];
-          }
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-          if (j < nr) {
-            // the two row tiles' chains side by side (one hides in the other's latency) -- and, on the VAD wave, the 16 multiply-adds
-            // of the unit tile between them: lane = stream, unfused (src/vec_avx.h:732-736)
-            const int u = a_base + j;
-            const float *S = &L.fold.stage[(u / W) & 1][u % W][0][0][0];
-            v4f x = {0.f, 0.f, 0.f, 0.f}, w4 = {0.f, 0.f, 0.f, 0.f};
-            if (vad_wave) {
-              x = *reinterpret_cast<const v4f *>(S + lane * 4);
-              w4 = *reinterpret_cast<const v4f *>(L.fold.vadw + 16 * u);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_pre[j][0][e], bx[j][e], dacc[0], 0, 0, 0);
-              dacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_pre[j][1][e], bx[j][e], dacc[1], 0, 0, 0);
-              if (vad_wave) {
-                const v4f xc = x, wc = w4;
-                if (e < 3) {  // the next step's operands, requested before this step's adds
-                  x = *reinterpret_cast<const v4f *>(S + ((e + 1) * (GM * TS) + lane) * 4);
-                  w4 = *reinterpret_cast<const v4f *>(L.fold.vadw + 16 * u + 4 * (e + 1));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) vacc = vacc + wc[i] * xc[i];
-              }
-              __builtin_amdgcn_sched_barrier(0);  // (one chain step at a time: the VAD operands of a whole tile are 32 registers)
-            }
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of the blocks have returned)
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-          if (j < nr && lane == 0) flag_add1(&L.fold.consumed[a_base + j]);
-        chain_u = a_base + nr;
-        if (nr < BW) break;
-      }
-    }
-  };
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 2
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#endif
 #pragma unroll 1
   for (int ui = 0; ui < 24 / W; ui++) {
     const int u = wave + W * ui, unit0 = 16 * u + 4 * gq;
@@ -697,70 +571,36 @@ __device__ __forceinline__ void gru_body(const RnGroupDev &g, const RnModelDev &
         stg<v4f>(st, (unsigned)(((tile0 + t) * TS + n) * RN_GRU + unit0) * 4u, hn);
         stg<int>(himg, (unsigned)((tile0 + t) * (KT * 64 * 16) + frag_off(n, unit0)), pack4_g(hn[0], hn[1], hn[2], hn[3]));
       }
-      if constexpr (FOLD) {
-        // (a stream that keeps its state is a silent one: its network outputs are zeroed below, whatever its chains summed)
-        if (t == 0 && ui >= 2) {  // the block was used two rounds ago: every chain must be done with that unit tile (meanwhile this
-                                  // wave's own chains go on: a wave that only waited could be what the others wait for)
-          for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(flag_load(&L.fold.consumed[u - 2 * W])) < NOWN; spins++) {
-            if (owner) chain_burst();
-            __builtin_amdgcn_s_sleep(2);
-            if (spins > (1u << 24)) __builtin_trap();  // (seconds: a protocol error must end the launch, not hang the device)
-          }
-          asm volatile("" ::: "memory");
-        }
-        *reinterpret_cast<v4f *>(&L.fold.stage[ui & 1][wave][gq][TS * t + n][0]) = hn;
-      }
-    }
-    if constexpr (FOLD) {
-      asm volatile("" ::: "memory");  // (the flag is written AFTER the block: a wave's LDS writes execute in issue order)
-      if (lane == 0) flag_store(&L.fold.ready[u], 1);
-      GRU_TAP(4);
-      if (owner) chain_burst();
-#if RN_INSTRUMENT  // (the burst on its own: slots 1391 + ui)
-      if (dbg && layer == 0 && ui < 3) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg[1391 - (RN_DBG_CLK2 + 7) + ui] = (float)(n_ - tc); tc = n_; }
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 3
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
 #endif
-    } else {
-      GRU_TAP(4);
     }
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 4
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#else
+    GRU_TAP(4);
+#endif
 #undef GRU_TAP
   }
 #ifdef RN_GRU_LAB  // (the row-buffer check: lab/nn_gru_lab.hip)
   if (CHK) image_check(1);
 #endif
-  [[maybe_unused]] const unsigned long long clk_tail = (RN_INSTRUMENT && g.debug) ? __builtin_amdgcn_s_memtime() : 0;
-  if constexpr (FOLD) {
-    if (owner) {
-      __builtin_amdgcn_s_setprio(0);  // (what is left is mostly waiting for the younger waves: not at their expense)
-      for (unsigned spins = 0; chain_u < 24; spins++) {  // at most the last round, plus whatever a slower wave still owes
-        const int before = chain_u;
-        chain_burst();
-        if (chain_u < 24 && chain_u == before) __builtin_amdgcn_s_sleep(8);  // (nothing was there: look again in a while)
-        if (spins > (1u << 24)) __builtin_trap();  // (seconds: a protocol error must end the launch, not hang the device)
-      }
-      const ChainWhere c = chain_where();
-      if (layer < 2) {  // the partial sums go on to the next layer's launch
-        if (c.cs < N) {
-          stg<v4f>(g.gains, c.acc_off, dacc[0]);
-          stg<v4f>(g.gains, c.acc_off + 64u, dacc[1]);
-        }
-        if (vad_wave && c.vs < N) g.vad[c.vs] = vacc;
-      } else {  // src/rnn.c:56-58: bias, sigmoid; a silent stream's network did not run (src/denoise.c:474): its outputs are 0
-        const bool lv = c.cs < N && !g.silence[c.csc];
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++) {
-          const v4f bs = ldg<v4f>(m.dense_out.bias, (unsigned)(16 * rt + 4 * gq) * 4u);
-          v4f o;
-#pragma unroll
-          for (int r = 0; r < 4; r++) o[r] = lv ? sigmoid_x86(dacc[rt][r] + bs[r], lut) : 0.f;
-          if (c.cs < N) stg<v4f>(g.gains, c.acc_off + 64u * rt, o);
-        }
-        if (vad_wave && c.vs < N) g.vad[c.vs] = g.silence[c.vs] ? 0.f : sigmoid_x86(vacc + m.vad_dense.bias[0], lut);
-      }
-    }
-  }
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 5
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#endif
   if (dbg && tile0 * TS < N) {
     const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
-    if (FOLD && layer == 0) dbg[1394 - (RN_DBG_CLK2 + 7)] = (float)(clk3 - clk_tail);  // (the tail: what is left of the chains behind the last unit tile)
+#ifdef RN_GRU_LAB
+#define RN_FOLD_PART 7
+#include "lab/nn_gru_fold.inc"
+#undef RN_FOLD_PART
+#endif
     dbg[0] = (float)(clk1 - clk0);
     dbg[1] = (float)(clk2 - clk1);
     dbg[2] = (float)(clk3 - clk2);
