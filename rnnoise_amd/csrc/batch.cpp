@@ -39,6 +39,7 @@ size_t batch_layout(RnGroupDev &g, uint8_t *base, int n) {
   g.n_stride = n;
   g.mem_hp = carve<float>(p, 2 * N);
   g.pitch_ring = carve<float>(p, RN_RING_SIZE * N);
+  g.xlp_ring = carve<float>(p, RN_XRING_SIZE * N);
   g.synth_mem = carve<float>(p, RN_FRAME_SIZE * N);
   g.last_gain = carve<float>(p, N);
   g.last_period = carve<int>(p, N);
@@ -75,6 +76,7 @@ RnGroupDev group_view(const RnGroupDev &g, int first, int count) {
   v.n_streams = count;
   v.mem_hp += 2 * f;
   v.pitch_ring += RN_RING_SIZE * f;
+  v.xlp_ring += RN_XRING_SIZE * f;
   v.synth_mem += RN_FRAME_SIZE * f;
   v.last_gain += f;
   v.last_period += f;

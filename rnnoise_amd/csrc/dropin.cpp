@@ -115,6 +115,7 @@ int pool_zero_row(StatePool *p, int slot, hipStream_t st) {
   const size_t N = p->batch->n;
   HIP_OK(hipMemsetAsync(v.mem_hp, 0, 2 * 4, st));
   HIP_OK(hipMemsetAsync(v.pitch_ring, 0, RN_RING_SIZE * 4, st));
+  HIP_OK(hipMemsetAsync(v.xlp_ring, 0, RN_XRING_SIZE * 4, st));
   HIP_OK(hipMemsetAsync(v.synth_mem, 0, RN_FRAME_SIZE * 4, st));
   HIP_OK(hipMemsetAsync(v.last_gain, 0, 4, st));
   HIP_OK(hipMemsetAsync(v.last_period, 0, 4, st));

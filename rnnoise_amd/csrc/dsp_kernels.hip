@@ -930,19 +930,30 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float *y4 = scr + SCR_Y4, *xc = scr + SCR_XC, *rsq = scr + SCR_SQ, *Dsyy = scr + SCR_D;
   int bp0 = 0, bp1 = 0, pitch_index = 0;
   float xx = 0.f;
-  // 2x decimation of pitch_buf into this wave's x_lp (src/pitch.c:155-166)
+  // pitch_buf 2x decimated (src/pitch.c:155-166) into this wave's x_lp: 864 consecutive samples of the decimated ring, which the
+  // high-pass kernel keeps beside the pitch ring (rn_dev.h: RN_XRING_SLOT) -- every decimated sample is a fixed function of three
+  // neighbouring ring samples, formed once when its slot is written, instead of 1728 samples decimated again by every frame that
+  // sees them.  Only x_lp[0], which has no left neighbour (src/pitch.c:166), is formed here.
   auto decimate_to_xlp = [&]() {
-#pragma unroll 7
-    for (int t = 0; t < 14; t++) {  // 864 = 13.5 x 64; constant trip count so that the loads overlap (7 x 3 at a time)
-      const int i0 = lane + WAVE * t, i = i0 < 864 ? i0 : 863;  // clamp, not a branch
-      // pitch_buf[2i] sits at an even ring position, so {b, c} is one aligned 8-byte load that never straddles the wrap; the
-      // left neighbour may (sample 0 has none: its load is aimed at a valid address and dropped)
-      const unsigned pe = (unsigned)ring0 + 2u * (unsigned)i, pl_ = (unsigned)max((int)pe - 1, ring0);
-      const float2 bc = *reinterpret_cast<const float2 *>(ring + min(pe, pe - (unsigned)RN_RING_SIZE));
-      const float a = ring[min(pl_, pl_ - (unsigned)RN_RING_SIZE)], b = bc.x, c = bc.y;
-      float v = .5f * (.5f * (a + c) + b);
-      if (t == 0) v = (i == 0) ? .5f * (.5f * c + b) : v;  // the first output has no left neighbour (src/pitch.c:166)
-      xlp[i] = v;  // lanes past the end recompute and rewrite element 863 with the same value: no branch
+    const char *xring = reinterpret_cast<const char *>(g.xlp_ring + (size_t)s * RN_XRING_SIZE);
+    // byte offsets in 32 bits (the loads take the wave-uniform base as a scalar pair); sample i = lane + 64 t sits 256 t bytes behind
+    // sample `lane`; the last round (t = 13) has 32 samples: its upper lanes re-read and rewrite sample 863
+    const unsigned a0 = 4u * ((unsigned)ring0 / 2u + (unsigned)lane), a13 = 4u * ((unsigned)ring0 / 2u + 832u + (unsigned)min(lane, 31));
+    const float2 pb01 = *reinterpret_cast<const float2 *>(ring + ring0);  // (ring0 is even and < RN_RING_SIZE)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {  // 864 = 13.5 x 64: two rounds of 7 loads in flight
+      float v[7];
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        const unsigned a = 7 * h + t < 13 ? a0 + 256u * (7 * h + t) : a13;
+        v[t] = *reinterpret_cast<const float *>(xring + min(a, a - 4u * (unsigned)RN_XRING_SIZE));
+      }
+      if (h == 0 && lane == 0) v[0] = .5f * (.5f * pb01.y + pb01.x);
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        if (7 * h + t < 13) xlp[lane + WAVE * (7 * h + t)] = v[t];
+        else xlp[832 + min(lane, 31)] = v[t];
+      }
     }
   };
   // One-row workgroups: the 5 autocorrelation lags behind the FIR taps are formed HERE, by two spare waves (lags 0..3 on the

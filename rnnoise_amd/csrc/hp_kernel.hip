@@ -28,7 +28,7 @@
 #ifndef RN_HP_ATTR
 #define RN_HP_ATTR
 #endif
-extern "C" __global__ void __launch_bounds__(WAVE) RN_HP_ATTR
+extern "C" __global__ void __launch_bounds__(4 * WAVE) RN_HP_ATTR
 RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
   // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
   // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
@@ -36,8 +36,9 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   // bits 12-13: streams per wave = 64 >> k.  The kernel is bound by how many loads its waves keep in flight (one wave per SIMD at 64 streams
   // per wave and 65,536 streams: each lane's HBM round trips are its own), not by issue: half-empty waves are twice as many waves
   const int spw = WAVE >> ((mode >> 12) & 3);
-  const int s = blockIdx.x * spw + threadIdx.x;
-  if ((int)threadIdx.x >= spw || s >= g.n_streams) return;
+  // (one wave per workgroup; or, A/B, four whole waves: blockDim.x = 256, one wave per SIMD of the CU that gets the workgroup)
+  const int s = blockDim.x > WAVE ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * spw + threadIdx.x;
+  if ((blockDim.x == WAVE && (int)threadIdx.x >= spw) || s >= g.n_streams) return;
   // (race hunt, $RNNOISE_AMD_HP_AB: 256 = drain the wave's stores before the pitch ring is read back, 512 = raised issue
   //  priority, 1024 = drain the tap stores before the wave ends)
   if (RN_INSTRUMENT && (mode & 512)) __builtin_amdgcn_s_setprio(3);
@@ -46,6 +47,10 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
   const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)s * RN_FRAME_SIZE);
   float4 *y = reinterpret_cast<float4 *>(g.pitch_ring + (size_t)s * RN_RING_SIZE + slot * RN_FRAME_SIZE);
+  // the slot's 240 decimated samples (rn_dev.h: RN_XRING_SLOT) are formed from the filtered frame as it leaves the registers; the
+  // first one needs the last sample of the previous slot
+  float4 *y2 = reinterpret_cast<float4 *>(g.xlp_ring + (size_t)s * RN_XRING_SIZE + slot * RN_XRING_SLOT);
+  float left = g.pitch_ring[(size_t)s * RN_RING_SIZE + (slot * RN_FRAME_SIZE + RN_RING_SIZE - 1) % RN_RING_SIZE];
   // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
   // filtered: with one wave per SIMD nothing else hides the HBM round trip
   constexpr int BLK = RN_HP_BLK;  // float4 per block
@@ -75,6 +80,7 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
       m1 = (float)fma(na1, yd, xd);                                  \
       (yo) = yi;                                                     \
     }
+    float2 dec[BLK];
 #pragma unroll
     for (int j = 0; j < BLK; j++) {
       const float4 v = cur[j];
@@ -85,7 +91,12 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
         o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
       }
       y[blk * BLK + j] = o;
+      dec[j].x = .5f * (.5f * (left + o.y) + o.x);  // (src/pitch.c:155-160, the expression of the readers below)
+      dec[j].y = .5f * (.5f * (o.y + o.w) + o.z);
+      left = o.w;
     }
+#pragma unroll
+    for (int j = 0; j < BLK; j += 2) y2[(blk * BLK + j) / 2] = make_float4(dec[j].x, dec[j].y, dec[j + 1].x, dec[j + 1].y);
 #undef HP_STEP
   }
   if (apply_hp) {
@@ -105,51 +116,57 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   }
   {
     const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
-    const int ring0 = RN_RING0(slot);
-    // pitch_buf in blocks of 32 floats (8 float4); ring0 and the ring size are multiples of 32, so a block never
-    // straddles the wrap; the next block is requested before this one is consumed
+    const float *xring = g.xlp_ring + (size_t)s * RN_XRING_SIZE;
+    const int ring0 = RN_RING0(slot), x0 = ring0 / 2;
+    // x_lp = 864 consecutive samples of the decimated ring from x0 (a multiple of 16; the ring size is a multiple of 4: a float4
+    // never straddles the wrap), in blocks of BLK float4, the next block requested before this one is consumed.  The slot
+    // written above is read back by the lane that wrote it.
     auto block = [&](int b, float4 (&dst)[BLK]) {
-      int p = ring0 + 4 * BLK * b;
-      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
-      const float4 *src = reinterpret_cast<const float4 *>(ring + p);
 #pragma unroll
-      for (int j = 0; j < BLK; j++) dst[j] = src[j];
+      for (int j = 0; j < BLK; j++) {
+        int p = x0 + 4 * (BLK * b + j);
+        p = (p >= RN_XRING_SIZE) ? p - RN_XRING_SIZE : p;
+        dst[j] = *reinterpret_cast<const float4 *>(xring + p);
+      }
     };
     float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
     float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
-    float prev = 0;                          // pitch_buf[4c-1]
+    // x_lp[0] has no left neighbour (src/pitch.c:166): formed here from pitch_buf[0], pitch_buf[1]
+    const float2 pb01 = *reinterpret_cast<const float2 *>(ring + ring0);
+    const float xlp0 = .5f * (.5f * (pb01.y) + pb01.x);
     block(0, nxt);
-    for (int b = 0; b < RN_PITCH_BUF_SIZE / (4 * BLK); b++) {
+    static_assert((RN_PITCH_BUF_SIZE / 2) % (4 * BLK) == 0 && 860 % 4 == 0, "whole blocks; the tail terms are the last float4");
+    for (int b = 0; b < RN_PITCH_BUF_SIZE / 2 / (4 * BLK); b++) {
 #pragma unroll
       for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-      if (b + 1 < RN_PITCH_BUF_SIZE / (4 * BLK)) block(b + 1, nxt);
+      if (b + 1 < RN_PITCH_BUF_SIZE / 2 / (4 * BLK)) block(b + 1, nxt);
 #pragma unroll
       for (int j = 0; j < BLK; j++) {
         const int c = b * BLK + j;
         const float4 v = cur[j];
-        float xl[2];
-        xl[0] = (c == 0) ? .5f * (.5f * (v.y) + v.x) : .5f * (.5f * (prev + v.y) + v.x);  // t = 2c
-        xl[1] = .5f * (.5f * (v.y + v.w) + v.z);                                        // t = 2c+1
-        prev = v.w;
+        const float xl[4] = {c == 0 ? xlp0 : v.x, v.y, v.z, v.w};
+        if (c < 215) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int t = 2 * c + h;
-          const float x0 = xl[h];
-          if (t < 860) {
-            ac[0] = ac[0] + x0 * x0;
-            ac[1] = ac[1] + w1 * x0;
-            ac[2] = ac[2] + w2 * x0;
-            ac[3] = ac[3] + w3 * x0;
-            ac[4] = ac[4] + w4 * x0;
-          } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
-            const int e = t - 860;
-            d[0] = d[0] + x0 * x0;
-            if (e >= 1) d[1] = d[1] + x0 * w1; else ac[1] = ac[1] + w1 * x0;
-            if (e >= 2) d[2] = d[2] + x0 * w2; else ac[2] = ac[2] + w2 * x0;
-            if (e >= 3) d[3] = d[3] + x0 * w3; else ac[3] = ac[3] + w3 * x0;
-            ac[4] = ac[4] + w4 * x0;
+          for (int h = 0; h < 4; h++) {
+            const float x0_ = xl[h];
+            ac[0] = ac[0] + x0_ * x0_;
+            ac[1] = ac[1] + w1 * x0_;
+            ac[2] = ac[2] + w2 * x0_;
+            ac[3] = ac[3] + w3 * x0_;
+            ac[4] = ac[4] + w4 * x0_;
+            w4 = w3; w3 = w2; w2 = w1; w1 = x0_;
           }
-          w4 = w3; w3 = w2; w2 = w1; w1 = x0;
+        } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float x0_ = xl[e];
+            d[0] = d[0] + x0_ * x0_;
+            if (e >= 1) d[1] = d[1] + x0_ * w1; else ac[1] = ac[1] + w1 * x0_;
+            if (e >= 2) d[2] = d[2] + x0_ * w2; else ac[2] = ac[2] + w2 * x0_;
+            if (e >= 3) d[3] = d[3] + x0_ * w3; else ac[3] = ac[3] + w3 * x0_;
+            ac[4] = ac[4] + w4 * x0_;
+            w4 = w3; w3 = w2; w2 = w1; w1 = x0_;
+          }
         }
       }
     }
@@ -278,6 +295,16 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 #pragma unroll
     for (int i = 0; i < 2; i++)
       if (lane + 64 * i < RN_FRAME_SIZE / 4) y[lane + 64 * i] = src[lane + 64 * i];
+    // ... and the slot's 240 decimated samples -> the decimated ring (rn_dev.h: RN_XRING_SLOT), which the analysis kernel reads
+    {
+      float *y2 = g.xlp_ring + (size_t)s * RN_XRING_SIZE + slot * RN_XRING_SLOT;
+      const float *nb = L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int t = lane + 64 * i;
+        if (t < RN_XRING_SLOT) y2[t] = .5f * (.5f * (nb[2 * t - 1] + nb[2 * t + 1]) + nb[2 * t]);
+      }
+    }
     // a listed row whose analysis runs as a four-wave workgroup gets its 5 FIR taps there, on a spare wave, beside the
     // transform of X (rn_analysis_rows_kernel): the lags, a third of this kernel's time, are not formed here (bit 8 of
     // slot_arg set by the launcher: they ARE wanted -- the one-wave analysis of $RNNOISE_AMD_ROWS_K1=1)
@@ -332,7 +359,6 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 #define RN_HP_ONE_MAX 5120
 #define RN_HP_ONE_MAX_PIPELINED 3072
 #define RN_HP_SPW 64  // streams per wave of the lane = stream kernel
-#define RN_HP_LEAN_MIN 32768
 extern "C" __global__ void rn_hp_lean_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_lean.hip
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
@@ -365,13 +391,16 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
     return v == 16 ? 2 : (v == 32 ? 1 : 0);
   }();
   const int spw = WAVE >> spw_shift;
-  // the lean form (hp_lean.hip: 16-sample blocks, at most 64 VGPRs) inside pipelined calls: a wave of it fits a SIMD BESIDE four
-  // analysis waves (4 x 112 + 64 = 512 registers) instead of taking the place of one ($RNNOISE_AMD_HP_LEAN = 0 | 1, A/B)
-  // measured, each pair inside one call: 65,536 streams 35.9 -> 36.1 M frames/s (+0.5 %; the high-pass itself 0.45 -> 0.33 ms inside the
-  // pipeline), sparser blob 32,768: +0.9 %, 16,384: -2.2 % -- so from RN_HP_LEAN_MIN streams up
-  static const int lean_env = [] { const char *e = getenv("RNNOISE_AMD_HP_LEAN"); return e ? atoi(e) : -1; }();
-  const bool lean = (lean_env >= 0 ? lean_env != 0 : g->n_streams >= RN_HP_LEAN_MIN) && beside_others && !slp;
-  RN_LAUNCH(slp ? rn_hp_slp_kernel : (lean ? rn_hp_lean_kernel : rn_hp_kernel), dim3((g->n_streams + spw - 1) / spw), dim3(WAVE), 0, st, e0, done, *g,
+  // the lean form (hp_lean.hip: 16-sample blocks, at most 64 VGPRs): a wave of it fits a SIMD BESIDE four analysis waves (4 x 112 + 64 =
+  // 512 registers) instead of taking the place of one.  $RNNOISE_AMD_HP_LEAN = 1 selects it inside pipelined calls.  It was the default
+  // from 32,768 streams while the autocorrelation pass re-read the whole pitch ring (+0.5 % at 65,536 streams); over the decimated ring
+  // (round 6) the 32-sample form is the faster one at 65,536 streams (36.1-36.3 against 35.8-35.9 M frames/s, four pairs in one call) and
+  // equal within 0.3 % on the sparser model at 32,768: profiles/r6_xlp_ring.txt
+  static const int lean_env = [] { const char *e = getenv("RNNOISE_AMD_HP_LEAN"); return e ? atoi(e) : 0; }();
+  const bool lean = lean_env != 0 && beside_others && !slp;
+  static const int wpb = [] { const char *e = RN_LAB_ENV("HP_WPB"); return e && atoi(e) == 4 ? 4 : 1; }();  // (A/B: waves per workgroup)
+  const int per_block = wpb > 1 ? wpb * WAVE : spw;
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : (lean ? rn_hp_lean_kernel : rn_hp_kernel), dim3((g->n_streams + per_block - 1) / per_block), dim3(wpb * WAVE), 0, st, e0, done, *g,
             static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
   return hipGetLastError();
 }

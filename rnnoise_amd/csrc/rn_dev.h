@@ -45,6 +45,14 @@
 // kernel may run up to two frames ahead (it writes slot t+1 or t+2) without touching what is being read.
 #define RN_RING_SLOTS 6
 #define RN_RING_SIZE (RN_RING_SLOTS * RN_FRAME_SIZE)
+// ... and beside it the same ring 2x DECIMATED (src/pitch.c:155-160: x_lp[i] = .5 (.5 (x[2i-1] + x[2i+1]) + x[2i])): 240 samples per slot.
+// pitch_buf[0] always sits at an even ring position, so a decimated sample is a function of three neighbouring ring samples whichever
+// frame asks for it -- except x_lp[0], which has no left neighbour and is formed by its reader.  The high-pass kernel that writes a
+// slot of the ring writes the slot's 240 decimated samples too (it has the filtered frame in registers); its autocorrelation pass and
+// the analysis kernel then read 864 floats per frame instead of decimating 1728 again each: 3.4 KB per stream and frame less, in each.
+// Derived data: rebuilt by the state scatter kernel after an import, zero after a reset (as the ring).
+#define RN_XRING_SLOT (RN_FRAME_SIZE / 2)
+#define RN_XRING_SIZE (RN_RING_SLOTS * RN_XRING_SLOT)
 // ring position of pitch_buf[0] when the newest frame sits in `slot` (its last sample = pitch_buf[1727])
 #define RN_RING0(slot) (((slot) * RN_FRAME_SIZE + RN_RING_SIZE - (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE)) % RN_RING_SIZE)
 
@@ -108,6 +116,7 @@ struct RnGroupDev {
   // persistent per-stream state
   float *mem_hp;       // [N][2]
   float *pitch_ring;   // [N][RN_RING_SIZE = 2880] ring of high-passed frames; pitch_buf (src/denoise.c:76) = its latest 1728 samples
+  float *xlp_ring;     // [N][RN_XRING_SIZE = 1440] the same ring 2x decimated (derived: see RN_XRING_SLOT)
   float *synth_mem;    // [N][480]
   float *last_gain;    // [N]
   int *last_period;    // [N]

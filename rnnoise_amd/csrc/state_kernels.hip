@@ -46,6 +46,14 @@ rn_state_scatter_kernel(RnGroupDev g, const float *__restrict__ flat, int newest
     const int i = (p - ring0 + RN_RING_SIZE) % RN_RING_SIZE;
     ring[p] = i < RN_PITCH_BUF_SIZE ? f[RN_OFF_PITCH_BUF + i] : 0.f;
   }
+  // the decimated ring is derived data (rn_dev.h: RN_XRING_SLOT): sample q = the high-pass kernel's expression over ring positions
+  // 2q-1, 2q, 2q+1 as just written (zeros outside pitch_buf)
+  float *xring = g.xlp_ring + s * RN_XRING_SIZE;
+  auto at = [&](int p) {
+    const int i = (p - ring0 + 2 * RN_RING_SIZE) % RN_RING_SIZE;
+    return i < RN_PITCH_BUF_SIZE ? f[RN_OFF_PITCH_BUF + i] : 0.f;
+  };
+  for (int q = threadIdx.x; q < RN_XRING_SIZE; q += blockDim.x) xring[q] = .5f * (.5f * (at(2 * q - 1) + at(2 * q + 1)) + at(2 * q));
   for (int w = RN_OFF_SYNTHESIS + threadIdx.x; w < RN_STATE_FLOATS; w += blockDim.x) {
     const float v = f[w];
     if (w < RN_OFF_PITCH_BUF) g.synth_mem[s * RN_FRAME_SIZE + (w - RN_OFF_SYNTHESIS)] = v;
