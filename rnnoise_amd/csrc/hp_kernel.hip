@@ -39,8 +39,8 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   // (one wave per workgroup; or, A/B, four whole waves: blockDim.x = 256, one wave per SIMD of the CU that gets the workgroup)
   const int s = blockDim.x > WAVE ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * spw + threadIdx.x;
   if ((blockDim.x == WAVE && (int)threadIdx.x >= spw) || s >= g.n_streams) return;
-  // (race hunt, $RNNOISE_AMD_HP_AB: 256 = drain the wave's stores before the pitch ring is read back, 512 = raised issue
-  //  priority, 1024 = drain the tap stores before the wave ends)
+  // (race hunt, $RNNOISE_AMD_HP_AB: 512 = raised issue priority, 1024 = drain the tap stores before the wave ends; 256 drained the
+  //  wave's stores before the pitch ring was read back -- nothing is read back any more)
   if (RN_INSTRUMENT && (mode & 512)) __builtin_amdgcn_s_setprio(3);
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
@@ -50,9 +50,15 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
   // the slot's 240 decimated samples (rn_dev.h: RN_XRING_SLOT) are formed from the filtered frame as it leaves the registers; the
   // first one needs the last sample of the previous slot
   float4 *y2 = reinterpret_cast<float4 *>(g.xlp_ring + (size_t)s * RN_XRING_SIZE + slot * RN_XRING_SLOT);
-  float left = g.pitch_ring[(size_t)s * RN_RING_SIZE + (slot * RN_FRAME_SIZE + RN_RING_SIZE - 1) % RN_RING_SIZE];
-  // 32 samples (one 128-byte line per stream) per block, the next block's 8 loads in flight while this one is
-  // filtered: with one wave per SIMD nothing else hides the HBM round trip
+  const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
+  const float *xring = g.xlp_ring + (size_t)s * RN_XRING_SIZE;
+  const int ring0 = RN_RING0(slot), x0 = ring0 / 2;
+  float left = ring[(slot * RN_FRAME_SIZE + RN_RING_SIZE - 1) % RN_RING_SIZE];
+  // x_lp[0] has no left neighbour (src/pitch.c:166): formed here from pitch_buf[0], pitch_buf[1]
+  const float2 pb01 = *reinterpret_cast<const float2 *>(ring + ring0);
+  const float xlp0 = .5f * (.5f * (pb01.y) + pb01.x);
+  // BLK float4 (32 samples = one 128-byte line per stream at BLK = 8) per block, the next block's loads in flight while this one is
+  // consumed: with one wave per SIMD nothing else hides the HBM round trip
   constexpr int BLK = RN_HP_BLK;  // float4 per block
   float4 cur[BLK], nxt[BLK];
   const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
@@ -63,12 +69,73 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
     }
     return x[idx];
   };
+
+  // ---- the serial half of rnn_pitch_downsample (src/pitch.c:146-214) rides along: 5-lag autocorrelation of the 2x decimated
+  // pitch_buf (src/celt_lpc.c:92-174), lag window, order-4 Levinson (src/celt_lpc.c:38-89) -> the 5 FIR taps.  In the wave-per-frame
+  // kernel these 5 chains of 864 steps used 5 lanes of 64; here every lane runs them over its own stream, keeping the last 4
+  // decimated samples in registers.  For sample t and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for
+  // lag k: terms i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
+  // Order of the work (round 6): FIRST the 624 decimated samples that older frames left in the decimated ring (no dependence on
+  // this frame: 156 float4 from x0, the ring size a multiple of 4 so that a float4 never straddles the wrap), THEN the frame itself,
+  // block by block: biquad -> ring slot -> its 16 decimated samples -> decimated slot AND straight on into the chains.  The new
+  // samples are never read back, and the frame's first block is requested while the last old block is consumed.
+  float ac[5] = {0, 0, 0, 0, 0};
+  float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
+#define AC_MAIN(xv)                      \
+  {                                      \
+    const float x0_ = (xv);              \
+    ac[0] = ac[0] + x0_ * x0_;           \
+    ac[1] = ac[1] + w1 * x0_;            \
+    ac[2] = ac[2] + w2 * x0_;            \
+    ac[3] = ac[3] + w3 * x0_;            \
+    ac[4] = ac[4] + w4 * x0_;            \
+    w4 = w3; w3 = w2; w2 = w1; w1 = x0_; \
+  }
+  // t = 860 + e: term i = t-k is < 860 for k > e, else it belongs to the tail
+#define AC_TAIL(xv, e)                                                        \
+  {                                                                           \
+    const float x0_ = (xv);                                                   \
+    d[0] = d[0] + x0_ * x0_;                                                  \
+    if ((e) >= 1) d[1] = d[1] + x0_ * w1; else ac[1] = ac[1] + w1 * x0_;      \
+    if ((e) >= 2) d[2] = d[2] + x0_ * w2; else ac[2] = ac[2] + w2 * x0_;      \
+    if ((e) >= 3) d[3] = d[3] + x0_ * w3; else ac[3] = ac[3] + w3 * x0_;      \
+    ac[4] = ac[4] + w4 * x0_;                                                 \
+    w4 = w3; w3 = w2; w2 = w1; w1 = x0_;                                      \
+  }
+  constexpr int OLD4 = (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 2 / 4;  // 156 float4 of old decimated samples
+  constexpr int OLD_BLOCKS = (OLD4 + BLK - 1) / BLK, NEW_BLOCKS = RN_FRAME_SIZE / 4 / BLK;
+  static_assert(RN_FRAME_SIZE / 4 % BLK == 0 && BLK % 2 == 0 && (RN_PITCH_BUF_SIZE / 2 - 860) == 4, "whole frame blocks; the tail terms are the frame's last two float4");
+  auto old_block = [&](int b, float4 (&dst)[BLK]) {
 #pragma unroll
-  for (int j = 0; j < BLK; j++) nxt[j] = load4(j);
-  for (int blk = 0; blk < RN_FRAME_SIZE / 4 / BLK; blk++) {
+    for (int j = 0; j < BLK; j++) {
+      int p = x0 + 4 * min(BLK * b + j, OLD4 - 1);  // (a partial last block re-reads its last float4 and drops it)
+      p = (p >= RN_XRING_SIZE) ? p - RN_XRING_SIZE : p;
+      dst[j] = *reinterpret_cast<const float4 *>(xring + p);
+    }
+  };
+  old_block(0, nxt);
+  for (int b = 0; b < OLD_BLOCKS; b++) {
 #pragma unroll
     for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-    if (blk + 1 < RN_FRAME_SIZE / 4 / BLK) {
+    if (b + 1 < OLD_BLOCKS) {
+      old_block(b + 1, nxt);
+    } else {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) nxt[j] = load4(j);
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      const int c = b * BLK + j;
+      if (OLD4 % BLK == 0 || c < OLD4) {
+        const float4 v = cur[j];
+        AC_MAIN(c == 0 ? xlp0 : v.x) AC_MAIN(v.y) AC_MAIN(v.z) AC_MAIN(v.w)
+      }
+    }
+  }
+  for (int blk = 0; blk < NEW_BLOCKS; blk++) {
+#pragma unroll
+    for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
+    if (blk + 1 < NEW_BLOCKS) {
 #pragma unroll
       for (int j = 0; j < BLK; j++) nxt[j] = load4((blk + 1) * BLK + j);
     }
@@ -91,87 +158,32 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
         o = v;  // training frames arrive already filtered by the caller's mixer (src/dump_features.c)
       }
       y[blk * BLK + j] = o;
-      dec[j].x = .5f * (.5f * (left + o.y) + o.x);  // (src/pitch.c:155-160, the expression of the readers below)
+      dec[j].x = .5f * (.5f * (left + o.y) + o.x);  // (src/pitch.c:155-160)
       dec[j].y = .5f * (.5f * (o.y + o.w) + o.z);
       left = o.w;
     }
+#undef HP_STEP
 #pragma unroll
     for (int j = 0; j < BLK; j += 2) y2[(blk * BLK + j) / 2] = make_float4(dec[j].x, dec[j].y, dec[j + 1].x, dec[j + 1].y);
-#undef HP_STEP
+    if (blk + 1 < NEW_BLOCKS) {
+#pragma unroll
+      for (int j = 0; j < BLK; j++) { AC_MAIN(dec[j].x) AC_MAIN(dec[j].y) }
+    } else {  // the frame's last block ends with decimated samples 860..863
+#pragma unroll
+      for (int j = 0; j < BLK - 2; j++) { AC_MAIN(dec[j].x) AC_MAIN(dec[j].y) }
+      float d[5] = {0, 0, 0, 0, 0};
+      AC_TAIL(dec[BLK - 2].x, 0) AC_TAIL(dec[BLK - 2].y, 1) AC_TAIL(dec[BLK - 1].x, 2) AC_TAIL(dec[BLK - 1].y, 3)
+#pragma unroll
+      for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
+    }
   }
+#undef AC_MAIN
+#undef AC_TAIL
   if (apply_hp) {
     g.mem_hp[2 * s] = m0;
     g.mem_hp[2 * s + 1] = m1;
   }
-
-  // ---- rnn_pitch_downsample's serial half (src/pitch.c:146-214): 2x decimation, 5-lag autocorrelation
-  // (src/celt_lpc.c:92-174), lag window, order-4 Levinson (src/celt_lpc.c:38-89) -> the 5 FIR taps.
-  // In the wave-per-frame kernel these 5 chains of 864 steps used 5 lanes of 64; here every lane
-  // streams its own pitch_buf once, keeping the last 4 decimated samples in registers.  For sample t
-  // and lag k the product xlp[t-k]*xlp[t] is term i = t-k of the reference's sum for lag k: terms
-  // i < 860 go to the main chain (rnn_pitch_xcorr over fastN), later ones to the tail chain `d`.
-  if (RN_INSTRUMENT && (mode & 256)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-  }
   {
-    const float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
-    const float *xring = g.xlp_ring + (size_t)s * RN_XRING_SIZE;
-    const int ring0 = RN_RING0(slot), x0 = ring0 / 2;
-    // x_lp = 864 consecutive samples of the decimated ring from x0 (a multiple of 16; the ring size is a multiple of 4: a float4
-    // never straddles the wrap), in blocks of BLK float4, the next block requested before this one is consumed.  The slot
-    // written above is read back by the lane that wrote it.
-    auto block = [&](int b, float4 (&dst)[BLK]) {
-#pragma unroll
-      for (int j = 0; j < BLK; j++) {
-        int p = x0 + 4 * (BLK * b + j);
-        p = (p >= RN_XRING_SIZE) ? p - RN_XRING_SIZE : p;
-        dst[j] = *reinterpret_cast<const float4 *>(xring + p);
-      }
-    };
-    float ac[5] = {0, 0, 0, 0, 0}, d[5] = {0, 0, 0, 0, 0};
-    float w1 = 0, w2 = 0, w3 = 0, w4 = 0;  // xlp[t-1..t-4]; zeros before the start add exact +0 products
-    // x_lp[0] has no left neighbour (src/pitch.c:166): formed here from pitch_buf[0], pitch_buf[1]
-    const float2 pb01 = *reinterpret_cast<const float2 *>(ring + ring0);
-    const float xlp0 = .5f * (.5f * (pb01.y) + pb01.x);
-    block(0, nxt);
-    static_assert((RN_PITCH_BUF_SIZE / 2) % (4 * BLK) == 0 && 860 % 4 == 0, "whole blocks; the tail terms are the last float4");
-    for (int b = 0; b < RN_PITCH_BUF_SIZE / 2 / (4 * BLK); b++) {
-#pragma unroll
-      for (int j = 0; j < BLK; j++) cur[j] = nxt[j];
-      if (b + 1 < RN_PITCH_BUF_SIZE / 2 / (4 * BLK)) block(b + 1, nxt);
-#pragma unroll
-      for (int j = 0; j < BLK; j++) {
-        const int c = b * BLK + j;
-        const float4 v = cur[j];
-        const float xl[4] = {c == 0 ? xlp0 : v.x, v.y, v.z, v.w};
-        if (c < 215) {
-#pragma unroll
-          for (int h = 0; h < 4; h++) {
-            const float x0_ = xl[h];
-            ac[0] = ac[0] + x0_ * x0_;
-            ac[1] = ac[1] + w1 * x0_;
-            ac[2] = ac[2] + w2 * x0_;
-            ac[3] = ac[3] + w3 * x0_;
-            ac[4] = ac[4] + w4 * x0_;
-            w4 = w3; w3 = w2; w2 = w1; w1 = x0_;
-          }
-        } else {  // t = 860..863: term i = t-k is < 860 for k > t-860, else it belongs to the tail
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const float x0_ = xl[e];
-            d[0] = d[0] + x0_ * x0_;
-            if (e >= 1) d[1] = d[1] + x0_ * w1; else ac[1] = ac[1] + w1 * x0_;
-            if (e >= 2) d[2] = d[2] + x0_ * w2; else ac[2] = ac[2] + w2 * x0_;
-            if (e >= 3) d[3] = d[3] + x0_ * w3; else ac[3] = ac[3] + w3 * x0_;
-            ac[4] = ac[4] + w4 * x0_;
-            w4 = w3; w3 = w2; w2 = w1; w1 = x0_;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) ac[k] = ac[k] + d[k];
     float taps[5];
     rn_fir_taps_from_ac(ac, taps);  // (lag window, Levinson, bandwidth expansion: rn_dev.h)
     float *o = g.lpc2 + ((size_t)slot * g.n_stride + s) * 8;  // one copy per ring slot: K0 runs up to 2 frames ahead of K1
@@ -197,13 +209,13 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
 // the other in a lane, the 2x decimation is spread over the wave, and global memory is touched in coalesced rows only
 // (frame and pitch_buf come in through LDS).  43 us -> 22 us for one stream (the biquad chain alone is ~8 us).
 // ---------------------------------------------------------------------------------------------
-// One array, used three times over (round 5: 12.5 -> 6.9 KB per wave, so that 16 waves fit a CU and a 4,096-stream batch is ONE round):
-//   pb[0 .. 1727]     pitch_buf of this frame: 1248 old samples from the ring, then the 480 new ones --
-//   pb[1248 .. 1727]  first the UNFILTERED frame: the biquad runs in place (a block's samples are in registers, and the next block's
-//                     too, before its outputs are stored);
-//   pb[0 .. 935]      finally the decimated signal (+ zeros for the reads of the idle lanes of the lag chains): the 2x decimation runs
-//                     in place as well -- pass i reads samples 128 i - 1 .. 128 i + 127 and then writes 64 i .. 64 i + 63, which no
-//                     later pass reads.
+// One array (6.9 KB per wave: 16 waves fit a CU and a 4,096-stream batch is ONE round):
+//   pb[0 .. 623]      the 624 decimated samples of pitch_buf that older frames left in the decimated ring (rn_dev.h: RN_XRING_SLOT),
+//   pb[624 .. 863]    the frame's own 240, formed once the biquad is through; + zeros up to 935 for the reads of the idle lanes of the
+//                     lag chains;
+//   pb[1248 .. 1727]  first the UNFILTERED frame, then the filtered one: the biquad runs in place (a block's samples are in registers,
+//                     and the next block's too, before its outputs are stored).
+// (Rounds 1-5 loaded the 1248 old samples of the pitch ring and decimated all 864 in place: 14 passes instead of 4.)
 struct HpOneLds {
   float pb[RN_PITCH_BUF_SIZE];
 };
@@ -222,10 +234,17 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
   float *ring = g.pitch_ring + (size_t)s * RN_RING_SIZE;
   const int ring0 = RN_RING0(slot);
-  {  // frame -> xin (120 float4), old part of pitch_buf -> pb (312 float4; ring0 and the ring size are multiples of 32)
+  const float *xring = g.xlp_ring + (size_t)s * RN_XRING_SIZE;
+  // what the decimated signal needs of the undecimated one: the last sample of the previous slot (left neighbour of the slot's first
+  // decimated sample) and pitch_buf[0], pitch_buf[1] (x_lp[0] has no left neighbour: src/pitch.c:166)
+  const float left = ring[(slot * RN_FRAME_SIZE + RN_RING_SIZE - 1) % RN_RING_SIZE];
+  const float2 pb01 = *reinterpret_cast<const float2 *>(ring + ring0);
+  {  // frame -> pb[1248..] (120 float4); the 624 decimated samples older frames left in the decimated ring -> pb[0..623] (156 float4 from
+     // ring0 / 2, a multiple of 16; the decimated ring's size is a multiple of 4, so a float4 never straddles the wrap)
     const float4 *x = reinterpret_cast<const float4 *>(in_row);
     const short4 *x16 = reinterpret_cast<const short4 *>(reinterpret_cast<const short *>(in) + (size_t)s * RN_FRAME_SIZE);
-    float4 f[2], o[5];
+    constexpr int OLD4 = (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 2 / 4;
+    float4 f[2], o[3];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int q = min(lane + 64 * i, RN_FRAME_SIZE / 4 - 1);  // (lanes past the end re-read the last 16 bytes and drop them)
@@ -237,18 +256,18 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
       }
     }
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int q = min(lane + 64 * i, (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4 - 1);
-      int p = ring0 + 4 * q;
-      p = (p >= RN_RING_SIZE) ? p - RN_RING_SIZE : p;
-      o[i] = *reinterpret_cast<const float4 *>(ring + p);
+    for (int i = 0; i < 3; i++) {
+      const int q = min(lane + 64 * i, OLD4 - 1);
+      int p = ring0 / 2 + 4 * q;
+      p = (p >= RN_XRING_SIZE) ? p - RN_XRING_SIZE : p;
+      o[i] = *reinterpret_cast<const float4 *>(xring + p);
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
       if (lane + 64 * i < RN_FRAME_SIZE / 4) reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE))[lane + 64 * i] = f[i];
 #pragma unroll
-    for (int i = 0; i < 5; i++)
-      if (lane + 64 * i < (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
+    for (int i = 0; i < 3; i++)
+      if (lane + 64 * i < OLD4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
   }
   __syncthreads();
   // rnn_biquad (src/denoise.c:409-419), once per wave: every lane reads the same samples and computes the same states
@@ -289,37 +308,30 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
     }
   }
   __syncthreads();
-  {  // the filtered frame -> its ring slot (coalesced); 2x decimation of the whole pitch_buf (src/pitch.c:155-160)
+  {  // the filtered frame -> its ring slot (coalesced); its 240 decimated samples (src/pitch.c:155-160) -> the decimated ring
+     // (rn_dev.h: RN_XRING_SLOT), which the analysis kernel reads, and behind the 624 old ones in pb
     float4 *y = reinterpret_cast<float4 *>(ring + slot * RN_FRAME_SIZE);
     const float4 *src = reinterpret_cast<const float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE));
 #pragma unroll
     for (int i = 0; i < 2; i++)
       if (lane + 64 * i < RN_FRAME_SIZE / 4) y[lane + 64 * i] = src[lane + 64 * i];
-    // ... and the slot's 240 decimated samples -> the decimated ring (rn_dev.h: RN_XRING_SLOT), which the analysis kernel reads
-    {
-      float *y2 = g.xlp_ring + (size_t)s * RN_XRING_SIZE + slot * RN_XRING_SLOT;
-      const float *nb = L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE);
+    float *y2 = g.xlp_ring + (size_t)s * RN_XRING_SIZE + slot * RN_XRING_SLOT;
+    const float *nb = L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE);
+    float *xlp = L.pb;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int t = lane + 64 * i;
-        if (t < RN_XRING_SLOT) y2[t] = .5f * (.5f * (nb[2 * t - 1] + nb[2 * t + 1]) + nb[2 * t]);
+    for (int i = 0; i < 4; i++) {
+      const int t = lane + 64 * i;
+      if (t < RN_XRING_SLOT) {
+        const float v = .5f * (.5f * ((t ? nb[2 * t - 1] : left) + nb[2 * t + 1]) + nb[2 * t]);
+        y2[t] = v;
+        xlp[(RN_PITCH_BUF_SIZE - RN_FRAME_SIZE) / 2 + t] = v;
       }
     }
     // a listed row whose analysis runs as a four-wave workgroup gets its 5 FIR taps there, on a spare wave, beside the
     // transform of X (rn_analysis_rows_kernel): the lags, a third of this kernel's time, are not formed here (bit 8 of
     // slot_arg set by the launcher: they ARE wanted -- the one-wave analysis of $RNNOISE_AMD_ROWS_K1=1)
     if (listed && !(slot_arg & 256)) return;
-    float *xlp = L.pb;  // (in place: see HpOneLds)
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-      const int t = lane + 64 * i;
-      if (t < 864) {
-        const float c = L.pb[2 * t], r = L.pb[2 * t + 1], l = L.pb[t ? 2 * t - 1 : 0];
-        __builtin_amdgcn_sched_barrier(0);  // (this pass's reads, every lane's, before its writes)
-        xlp[t] = (t == 0) ? .5f * (.5f * r + c) : .5f * (.5f * (l + r) + c);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    if (lane == 0) xlp[0] = .5f * (.5f * pb01.y + pb01.x);
     if (lane < 8) xlp[864 + lane] = 0;
     xlp[872 + lane] = 0;
   }
@@ -359,7 +371,6 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 #define RN_HP_ONE_MAX 5120
 #define RN_HP_ONE_MAX_PIPELINED 3072
 #define RN_HP_SPW 64  // streams per wave of the lane = stream kernel
-extern "C" __global__ void rn_hp_lean_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_lean.hip
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
 #else
@@ -391,16 +402,13 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
     return v == 16 ? 2 : (v == 32 ? 1 : 0);
   }();
   const int spw = WAVE >> spw_shift;
-  // the lean form (hp_lean.hip: 16-sample blocks, at most 64 VGPRs): a wave of it fits a SIMD BESIDE four analysis waves (4 x 112 + 64 =
-  // 512 registers) instead of taking the place of one.  $RNNOISE_AMD_HP_LEAN = 1 selects it inside pipelined calls.  It was the default
-  // from 32,768 streams while the autocorrelation pass re-read the whole pitch ring (+0.5 % at 65,536 streams); over the decimated ring
-  // (round 6) the 32-sample form is the faster one at 65,536 streams (36.1-36.3 against 35.8-35.9 M frames/s, four pairs in one call) and
-  // equal within 0.3 % on the sparser model at 32,768: profiles/r6_xlp_ring.txt
-  static const int lean_env = [] { const char *e = getenv("RNNOISE_AMD_HP_LEAN"); return e ? atoi(e) : 0; }();
-  const bool lean = lean_env != 0 && beside_others && !slp;
+  // (rounds 5-6 had a second build of this kernel with 16-sample blocks at 64 VGPRs -- rn_hp_lean_kernel, a wave of which fits a SIMD
+  // beside four analysis waves: +0.5 % at 65,536 streams while the autocorrelation pass re-read the whole pitch ring.  Over the decimated
+  // ring the 32-sample form is the faster one inside the pipeline too (profiles/r6_xlp_ring.txt), and with the chains fed from the
+  // biquad's registers the 64-register budget spills: gone.)
   static const int wpb = [] { const char *e = RN_LAB_ENV("HP_WPB"); return e && atoi(e) == 4 ? 4 : 1; }();  // (A/B: waves per workgroup)
   const int per_block = wpb > 1 ? wpb * WAVE : spw;
-  RN_LAUNCH(slp ? rn_hp_slp_kernel : (lean ? rn_hp_lean_kernel : rn_hp_kernel), dim3((g->n_streams + per_block - 1) / per_block), dim3(wpb * WAVE), 0, st, e0, done, *g,
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + per_block - 1) / per_block), dim3(wpb * WAVE), 0, st, e0, done, *g,
             static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
   return hipGetLastError();
 }

@@ -632,19 +632,19 @@ def test_throughput_kernels_at_small_sizes():
 
 
 def test_at_size_kernels_on_small_ragged_batches():
-    """The two kernels that only LARGE batches take by default -- the four-wave GRU layer kernel (rn_nn_gru_kernel: more 64-stream
-    groups than CUs) and the 61-VGPR high-pass (rn_hp_lean_kernel: >= 32,768 streams inside pipelined calls) -- forced onto the small
-    ragged cases ($RNNOISE_AMD_GRU_VARIANT=w4, $RNNOISE_AMD_HP_LEAN=1, with the latency kernels off and the layer-wise network from
-    size 0 up): n = 4 ... 130 streams against the oracle stream by stream, partial tiles, partial groups, partial waves.  The
-    default run of the same cases takes the eight-wave form (w8) and the 107-VGPR high-pass; tests/test_gpu_at_size.py has the ragged
-    batch at size (40,037 streams)."""
+    """The kernels that only LARGE batches take by default -- the four-wave GRU layer kernel (rn_nn_gru_kernel: more 64-stream
+    groups than CUs), the lane-per-stream high-pass (rn_hp_kernel: above 3,072 streams), the four-stream analysis workgroup -- forced
+    onto the small ragged cases ($RNNOISE_AMD_GRU_VARIANT=w4, with the latency kernels off and the layer-wise network from size 0
+    up): n = 4 ... 130 streams against the oracle stream by stream, partial tiles, partial groups, partial waves.  The default run of
+    the same cases takes the eight-wave form (w8) and the wave-per-stream high-pass; tests/test_gpu_at_size.py has the ragged batch at
+    size (40,037 streams)."""
     import os
     import subprocess
     import sys
     if os.environ.get("RNNOISE_AMD_NN_ONE_MAX"):
         pytest.skip("already inside a forced run")
     env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0", RNNOISE_AMD_K1_SPW="4", RNNOISE_AMD_NN_LAYERS_MIN="0",
-               RNNOISE_AMD_GRU_VARIANT="w4", RNNOISE_AMD_HP_LEAN="1")
+               RNNOISE_AMD_GRU_VARIANT="w4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, os.path.join(root, "tests", "test_blob_tools.py"), "-k",
                         "test_mfma_path_bit_exact or test_sparser_blob_on_ragged_batches or test_synthetic_models_on_gpu or test_s16_entry_points"],

@@ -34,7 +34,7 @@ def test_the_product_has_two_gru_layer_kernels_and_no_experiment(built):
         # every device kernel of the product, by name: a new one has to be put on this list on purpose
         all_kernels = set(re.findall(r"\b(rn_\w+_kernel)\.kd\b", built[p]))
         assert all_kernels == {
-            "rn_hp_kernel", "rn_hp_lean_kernel", "rn_hp_one_kernel",
+            "rn_hp_kernel", "rn_hp_one_kernel",
             "rn_analysis_kernel", "rn_analysis_single_kernel", "rn_analysis_rows_kernel", "rn_train_features_kernel",
             "rn_synthesis_kernel", "rn_synthesis_few_kernel",
             "rn_nn_vector_kernel", "rn_nn_one_kernel", "rn_nn_mfma_kernel", "rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_w8_kernel",
