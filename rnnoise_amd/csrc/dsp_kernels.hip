@@ -168,6 +168,33 @@ __device__ __forceinline__ float dct_lane(const float *in, const float *c, const
   return (float)(sum * tb.dct_scale);
 }
 
+// max of two floats as ONE v_max_f32.  fmaxf() is llvm.maxnum, whose operands the compiler first canonicalises (v_max_f32 v, v, v)
+// unless it can prove them quiet -- it cannot for values read from LDS -- although the instruction quiets a signalling NaN itself:
+// three instructions where one gives the same bits for every operand pair.  Used on the follower's 32-step dependent chain.
+__device__ __forceinline__ float max1(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// The log-energy follower of rnn_compute_frame_features (src/denoise.c:378-388) over ly[32] (log10 of the band energies, replaced in
+// place by the followed values); returns the frame's energy sum E.  The reference forms follow-1.5 in double and rounds the selected
+// maximum to float (src/denoise.c:381-386); follow-1.5 is exact in double, rounding is monotonic and the other operands are floats, so
+// (float)max(follow-1.5, b) == max(follow-1.5f, b): the whole recurrence stays in float, same bits.  (The reference's MAX16 / MIN16
+// ternaries as v_max_f32: the same value for every non-NaN operand pair -- at most the sign of a zero differs, when +0 meets -0, which
+// neither log10 nor these differences produce -- and one instruction instead of a compare, a select and the VCC wait between them.)
+__device__ __forceinline__ float log_follower(float *ly, const float *ex, bool store) {
+  float logMax = -2, follow = -2, E = 0;
+  for (int i = 0; i < RN_NB_BANDS; i++) {
+    const float fd = follow - 1.5f;
+    const float v = max1(logMax - 7, max1(fd, ly[i]));
+    logMax = max1(logMax, v);
+    follow = max1(fd, v);
+    E += ex[i];
+    if (store) ly[i] = v;
+  }
+  return E;
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int l) {  // l must be wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -822,6 +849,7 @@ struct AnalysisLds {
 #define MAIL_XX 3      //   <x, x> of remove_doubling
 #define MAIL_SYY0F 4   //   start energy of the fine find_best_pitch
 #define MAIL_T0 5      //   remove_doubling's T0 (int bits), for the wave that runs this stream's candidate dots
+#define MAIL_E 6       //   the frame's band-energy sum (behind `silence`), from the wave that ran the workgroup's log-energy followers
 // K1_STOP(k): instrumented build only -- the whole workgroup leaves the kernel at stop point k (tools/k1_prefix.sh runs the
 // kernel once per stop point under the PMC counters: the differences are each section's LDS cycles, bank conflicts, VALU
 // instructions and time).  Stop points sit where all waves of a workgroup pass together.
@@ -1196,18 +1224,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       for (int j = 0; j < RN_NB_BANDS; j++) dcol[j] = tb.dct[j * RN_NB_BANDS + (lane & 31)];
       if (lane < RN_NB_BANDS) Ly[lane] = rn_log_energy(ex0[lane], tb.log_tab);
       RN_WSYNC();
-      float e_sum = 0;
-      {
-        float logMax = -2, follow = -2;
-        for (int i = 0; i < RN_NB_BANDS; i++) {
-          const float fd = follow - 1.5f;
-          const float ly = fmaxf(logMax - 7, fmaxf(fd, Ly[i]));
-          logMax = fmaxf(logMax, ly);
-          follow = fmaxf(fd, ly);
-          e_sum += ex0[i];
-          if (lane == 0) Ly[i] = ly;
-        }
-      }
+      const float e_sum = log_follower(Ly, ex0, lane == 0);
       RN_WSYNC();
       if (lane < RN_NB_BANDS && in_range) {
         float f_lo = dct_lane(Ly, dcol, tb);
@@ -1357,6 +1374,22 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
         float *a = ARENA((lane >> 4) < SPW ? (lane >> 4) : 0).a;
         sweep_yy_lookup_row_x(a + SCR_XLP, a + SCR_YYL, a[SCR_MAIL + MAIL_XX], lane & 15);
         __builtin_amdgcn_s_setprio(1);
+      } else if (!solo) {
+        // nw3a, the one wave with nothing to do in this phase: log10 of the band energies and the log-energy follower (src/denoise.c:
+        // 378-388) of EVERY stream of the workgroup -- they need Ex only, in its arena since the first transform.  The follower is a
+        // 32-step dependent chain of ~10 instructions a step whatever the number of lanes: run by each wave for its own stream it cost
+        // four times the issue slots (~450 of a wave's 7,400 VALU instructions, profiles/r6_k1_follower.txt).  One row of 16 lanes per
+        // stream: two of the stream's 32 logarithms per lane, then the chain on the row's first lane.  Ly's place (over the dead fine
+        // cross-correlations) is written by nothing else until the features read it.
+        const int gq = lane >> 4, r = lane & 15;  // (SPW == 4 rows)
+        float *ag = ARENA(gq).a;
+        float *ly = ag + (SCR_MISC + 80 + 64);
+        const float *ex = ag + SCR_EX;
+        const float e0 = ex[r], e1 = ex[16 + r];
+        ly[r] = rn_log_energy(e0, tb.log_tab);
+        ly[16 + r] = rn_log_energy(e1, tb.log_tab);
+        RN_WSYNC();
+        if (r == 0) ag[SCR_MAIL + MAIL_E] = log_follower(ly, ex, true);
       }
       __syncthreads();
       if (!active) return;  // (that was the last barrier: the surplus waves of a one-row workgroup are done)
@@ -1498,29 +1531,17 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   float f_hi = 0;
   if (lane < RN_NB_BANDS) {
     f_hi = dct_lane(Exp, dctc, tb);
-    if (!solo) Ly[lane] = rn_log_energy(Ex[lane], tb.log_tab);
+    if (!solo && !spread) Ly[lane] = rn_log_energy(Ex[lane], tb.log_tab);
   }
   RN_WSYNC();
-  // log-energy follower + total energy: 32 serial steps, evaluated uniformly.  The reference forms
-  // follow-1.5 in double and rounds the selected maximum to float (src/denoise.c:381-386); follow-1.5 is
-  // exact in double, rounding is monotonic and the other operands are floats, so
-  // (float)max(follow-1.5, b) == max(follow-1.5f, b): the whole recurrence stays in float, same bits.
+  // log-energy follower + total energy (log_follower above): 32 serial steps
   float E = 0;
   if (solo) {  // (the follower and the first 32 features came from a spare wave during narrow phase 2)
     for (int i = 0; i < RN_NB_BANDS; i++) E += Ex[i];
+  } else if (spread) {  // (run for the whole workgroup by the idle wave of narrow phase 3: Ly holds the followed values)
+    E = mail[MAIL_E];
   } else {
-    float logMax = -2, follow = -2;
-    for (int i = 0; i < RN_NB_BANDS; i++) {
-      // (the reference's MAX16 / MIN16 ternaries as v_max_f32: the same value for every non-NaN operand pair -- at most the sign
-      //  of a zero differs, when +0 meets -0, which neither log10 nor these differences produce -- and one instruction instead
-      //  of a compare, a select and the VCC wait between them on this 32-step dependent chain)
-      const float fd = follow - 1.5f;
-      const float ly = fmaxf(logMax - 7, fmaxf(fd, Ly[i]));
-      logMax = fmaxf(logMax, ly);
-      follow = fmaxf(fd, ly);
-      E += Ex[i];
-      if (lane == 0) Ly[i] = ly;
-    }
+    E = log_follower(Ly, Ex, lane == 0);  // (evaluated uniformly by every lane)
   }
   RN_WSYNC();
   // inference: silent frames zero the features and skip the network (src/denoise.c:389-393);
