@@ -933,12 +933,14 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const GLOBAL_AS float *hw = (const GLOBAL_AS float *)hw_;
     int p0 = ring0 + start;
     p0 = (p0 >= RN_RING_SIZE) ? p0 - RN_RING_SIZE : p0;
-    const unsigned pl = (unsigned)p0 + (unsigned)lane;
+    // (byte offsets in 32 bits: the load then takes the wave-uniform ring base as a scalar pair + one offset register, instead of a
+    //  64-bit address formed per load)
+    const unsigned pl = 4u * ((unsigned)p0 + (unsigned)lane);
     float v[RN_WINDOW_SIZE / WAVE], w[RN_WINDOW_SIZE / WAVE];
 #pragma unroll
     for (int t = 0; t < RN_WINDOW_SIZE / WAVE; t++) {
-      const unsigned a = pl + WAVE * t;
-      v[t] = ring[min(a, a - (unsigned)RN_RING_SIZE)];
+      const unsigned a = pl + 4u * WAVE * t;
+      v[t] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + min(a, a - 4u * (unsigned)RN_RING_SIZE));
       const unsigned i = (unsigned)lane + WAVE * t;
       w[t] = hw[WAVE * t + WAVE <= RN_FRAME_SIZE ? i : (WAVE * t >= RN_FRAME_SIZE || i >= RN_FRAME_SIZE ? RN_WINDOW_SIZE - 1 - i : i)];
     }
@@ -1403,8 +1405,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     float yy = fmaxf(0.f, yyl[T0]);
     float best_xy = xy, best_yy = yy;
     if (dbg && lane == 0) { dbg[RN_DBG_DOTS] = xx; dbg[RN_DBG_DOTS + 1] = xy; dbg[RN_DBG_DOTS + 2] = yy; }
-    const float g0 = pitch_gain(xy, xx, yy);
-    float gg = g0;
+    float g0, gg;
     int cand = 0;  // which candidate won: 0 = T0, c = k-1 for T1(k)
     {
       // The reference loop (pitch.c:462-500) runs k = 2..15, stops at the first T1 < minperiod and keeps the
@@ -1419,7 +1420,11 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
       float xy1 = dots[2 + 2 * (k - 2)], xy2 = dots[3 + 2 * (k - 2)];
       xy1 = .5f * (xy1 + xy2);
       const float yy1 = .5f * (fmaxf(0.f, yyl[T1]) + fmaxf(0.f, yyl[T1b]));
-      const float g1 = pitch_gain(xy1, xx, yy1);
+      // (one evaluation of compute_pitch_gain -- a double-precision square root and a division, ~60 instructions -- for both uses:
+      //  lane 0 forms g0 of T0, which every threshold below needs, lanes 2..15 their own g1)
+      const float g1 = pitch_gain(lane == 0 ? xy : xy1, xx, lane == 0 ? yy : yy1);
+      g0 = lane_bcast(g1, 0);
+      gg = g0;
       float cont;
       int dT = T1 - prev_period;
       dT = dT < 0 ? -dT : dT;
@@ -1486,6 +1491,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
     const float2 *ftw2 = ftw;
     int lane2 = lane;
     asm volatile("" : "+s"(hw2), "+s"(ftw2), "+v"(lane2));
+    lane2 &= WAVE - 1;  // (its range, for the compiler: table indices formed from it then fold into the loads' immediate offsets)
     window_to_regs(pr, pi, RN_PITCH_BUF_SIZE - RN_WINDOW_SIZE - __builtin_amdgcn_readfirstlane(pitch_index), hw2);
     // X is read back from HBM/L2 (this wave wrote it; its stores are long complete), in the lane-owns-bins layout
 #pragma unroll
@@ -1528,11 +1534,7 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
 
   // ---- features (src/denoise.c:378-397) ----
   float *feat = g.features + (size_t)s * 68;
-  float f_hi = 0;
-  if (lane < RN_NB_BANDS) {
-    f_hi = dct_lane(Exp, dctc, tb);
-    if (!solo && !spread) Ly[lane] = rn_log_energy(Ex[lane], tb.log_tab);
-  }
+  if (!solo && !spread && lane < RN_NB_BANDS) Ly[lane] = rn_log_energy(Ex[lane], tb.log_tab);
   RN_WSYNC();
   // log-energy follower + total energy (log_follower above): 32 serial steps
   float E = 0;
@@ -1548,18 +1550,17 @@ __device__ __forceinline__ void analysis_body(const RnGroupDev &g, const RnTable
   // TRAINING build: features are always produced and "silence" means E < 0.1 (:389,:397)
   const int silence = TRAIN ? (((double)E < 0.1) ? 1 : 0) : (((double)E < 0.04) ? 1 : 0);
   const bool zero = !TRAIN && silence;
-  if (lane < RN_NB_BANDS && wr) {
-    float f_lo = 0;
-    if (!solo) {
-      f_lo = dct_lane(Ly, dctc, tb);
-      if (lane == 0) f_lo -= 12;
-      if (lane == 1) f_lo -= 4;
-      feat[lane] = zero ? 0.f : f_lo;
-    }
-    feat[RN_NB_BANDS + lane] = zero ? 0.f : f_hi;
-    if (TRAIN) {
-      tr.rec[(size_t)s * 98 + lane] = f_lo;
-      tr.rec[(size_t)s * 98 + RN_NB_BANDS + lane] = f_hi;
+  // the two DCTs (src/denoise.c:387,396) in ONE pass: lanes 0..31 the column sums over the followed log energies (features 0..31),
+  // lanes 32..63 the same columns over Exp (features 32..63) -- feature = lane.  (One-row workgroups: the first 32 exist already.)
+  {
+    const bool hi = solo || lane >= RN_NB_BANDS;
+    float f = dct_lane(hi ? Exp : Ly, dctc, tb);
+    if (!hi && lane == 0) f -= 12;
+    if (!hi && lane == 1) f -= 4;
+    const int fi = solo ? RN_NB_BANDS + lane : lane;
+    if (wr && (!solo || lane < RN_NB_BANDS)) {
+      feat[fi] = zero ? 0.f : f;
+      if (TRAIN) tr.rec[(size_t)s * 98 + fi] = f;
     }
   }
   if (lane == 0 && wr) {
