@@ -1684,6 +1684,35 @@ struct SynthPlace {
   int s, lane;
   char *lds;
 };
+// Where transform output b of a lane goes (src/denoise.c:213-216, 400-407).  The lane holds y[p], p = 64 b + pos, pos = fft_pos(lane) in
+// 0..63; time sample n = (960 - p) % 960.  lo = "p == 0 or p > 480" = n < 480: an output sample, out[n] = 960 y w[n] + synthesis_mem[n];
+// otherwise synthesis_mem[n - 480] = 960 y w[959 - n] = 960 y w[p - 1], n - 480 = 480 - p.  Returns the window index (n or p - 1) and sets
+// `mem` to the synthesis_mem index (n or 480 - p).  b is a compile-time constant wherever this is called (unrolled loops), so each case
+// is a constant plus pos or q = 63 - pos -- written out because the generic expression costs a signed modulo, two compares, an exec-mask
+// branch and a 64-bit address per b when the compiler does not know pos's range (15 instructions x 15: a tenth of the kernel).
+//   b = 0: lo iff pos == 0, and n = max(pos, 1) - 1 either way;   b = 1..6: never lo;   b = 7: lo iff pos > 32;   b = 8..14: always lo
+__device__ __forceinline__ unsigned synth_index(int b, unsigned pos, bool &lo, unsigned &mem) {
+  const unsigned q = 63u - pos;
+  if (b == 0) {
+    lo = pos == 0;
+    const unsigned n = max(pos, 1u) - 1u;
+    mem = lo ? 0u : 417u + q;
+    return n;
+  }
+  if (b < 7) {
+    lo = false;
+    mem = (417u - 64u * b) + q;
+    return (64u * b - 1u) + pos;
+  }
+  if (b == 7) {
+    lo = pos > 32u;
+    mem = lo ? 512u - pos : 32u - pos;
+    return lo ? 512u - pos : 447u + pos;
+  }
+  lo = true;
+  mem = (897u - 64u * b) + q;
+  return mem;
+}
 template <bool LATE>
 __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTablesDev &tb, float *__restrict__ out, int parity_arg, int prev_arg,
                                                const RnRows &rows, const SynthPlace *place = nullptr) {
@@ -1735,11 +1764,11 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
   if (!LATE) {
 #pragma unroll
     for (int b = 0; b < 15; b++) {
-      const int p = WAVE * b + pos;
-      const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
-      const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
-      wv[b] = tb.half_window[n];
-      smv[b] = lo ? sm[n] : 0.f;
+      bool lo;
+      unsigned mi;
+      const unsigned wi = synth_index(b, (unsigned)pos & 63u, lo, mi);
+      wv[b] = tb.half_window[wi];
+      smv[b] = lo ? sm[mi] : 0.f;
     }
   }
 
@@ -1830,22 +1859,23 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
   if (LATE) {
     int pos_late = pos;
     asm volatile("" : "+v"(pos_late), "+v"(yr[14]));
+    const unsigned pl = (unsigned)pos_late & 63u;  // (its range, for the compiler)
 #pragma unroll
     for (int b = 0; b < 15; b++) {
-      const int p = WAVE * b + pos_late;
-      const bool lo = p == 0 || p > RN_FRAME_SIZE;     // this position is an output sample (first half of the frame)
-      const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
-      wv[b] = tb.half_window[n];
-      smv[b] = lo ? sm[n] : 0.f;
+      bool lo;
+      unsigned mi;
+      const unsigned wi = synth_index(b, pl, lo, mi);
+      wv[b] = tb.half_window[wi];
+      smv[b] = lo ? sm[mi] : 0.f;
     }
   }
   // window + overlap-add (src/denoise.c:400-407), straight from the registers
   float *o = listed ? rows.io + (size_t)s * RN_ROW_IO + RN_FRAME_SIZE + 4 : out + (size_t)s * RN_FRAME_SIZE;
 #pragma unroll
   for (int b = 0; b < 15; b++) {
-    const int p = WAVE * b + pos;
-    const bool lo = p == 0 || p > RN_FRAME_SIZE;
-    const int n = lo ? (RN_WINDOW_SIZE - p) % RN_WINDOW_SIZE : p - 1;
+    bool lo;
+    unsigned n;  // (lo: the output sample's index; otherwise where the sample goes in synthesis_mem)
+    (void)synth_index(b, (unsigned)pos & 63u, lo, n);
     float v = (float)RN_WINDOW_SIZE * yr[b];
     v *= wv[b];
     if (lo) {
@@ -1857,7 +1887,7 @@ __device__ __forceinline__ void synthesis_body(const RnGroupDev &g, const RnTabl
         o[n] = r;
       }
     } else {
-      sm[RN_FRAME_SIZE - p] = v;
+      sm[n] = v;
     }
   }
   if (listed) {
