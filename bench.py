@@ -55,16 +55,17 @@ METRIC = "10ms frames/sec (48kHz mono) at N concurrent streams; % HBM roofline"
 
 # Algorithmic HBM bytes per stream-frame of each kernel; W is added to the network
 # kernel per LAUNCH from the model: the weights are read from HBM at most once per launch.
-# (round 6: pitch_buf is kept 2x decimated beside the ring -- rn_dev.h RN_XRING_SLOT -- so K0's autocorrelation pass and K1's
-#  downsampling read 864 floats where they read 1728: 3,456 - 948 fewer bytes for K0, 3,448 fewer for K1 than in rounds 1-5)
+# (round 6: pitch_buf is kept 2x decimated beside the ring -- rn_dev.h RN_XRING_SLOT -- so K0's autocorrelation pass reads the 624 OLD
+#  decimated samples where it read 1728 ring samples, the frame's own 240 going from the biquad's registers straight into the chains, and
+#  K1's downsampling reads 864 floats where it read 1728: 3,444 fewer bytes for K0, 3,448 fewer for K1 than in rounds 1-5)
 #   K0: input 1920 r + ring slot 1920 w + decimated slot 960 w + hp state 8 r + 8 w + last sample of the previous slot 4 r
-#       + decimated pitch_buf 3456 r + pitch_buf[0..1] 8 r (autocorrelation) + 5 taps 20 w
+#       + old decimated samples 2496 r + pitch_buf[0..1] 8 r (autocorrelation) + 5 taps 20 w
 #   K1: decimated pitch_buf 3456 + pitch_buf[0..1] 8 (downsample) + 2 x 3840 (windows) r, X re-read 3200 r, taps 20 r;
 #       X,P 7696 + E 384 + features 260 + flags 12 w
 #   K2: features 260 r, conv/GRU state 2 x (520 + 1024 + 4608), gains 128 + vad 4 w
 #   K3: X,P 7696 + E 2 x 384 + gains 128 + lastg 2 x 128 + synth_mem 2 x 1920 r/w + out 1920 w
 ALG_BYTES = {
-    "highpass": 1920 + 1920 + 960 + 16 + 4 + 3456 + 8 + 20,
+    "highpass": 1920 + 1920 + 960 + 16 + 4 + 2496 + 8 + 20,
     "analysis": (3456 + 8 + 3840 + 3840 + 3200 + 20) + (7696 + 384 + 260 + 12),
     "network": 260 + 2 * (520 + 1024 + 4608) + 128 + 4,
     "synthesis": 3848 + 3848 + 384 + 128 + 128 + 256 + 1920 + 1920 + 1920,

@@ -29,7 +29,7 @@ def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
 
 def test_algorithmic_bytes_match_design_table():
     # DESIGN.md section 4
-    assert bench.ALG_BYTES == {"highpass": 8304, "analysis": 22716, "network": 12696, "synthesis": 14352}
+    assert bench.ALG_BYTES == {"highpass": 7344, "analysis": 22716, "network": 12696, "synthesis": 14352}
     assert bench.waves_per_launch("analysis", 65536) == 65536 and bench.waves_per_launch("highpass", 65536) == 1024
     assert bench.waves_per_launch("network", 65536) == 1024 * 8 and bench.waves_per_launch("network", 17) == 16
 
