@@ -54,7 +54,7 @@ __device__ __forceinline__ float xlane_xor(float v, int lane) {
     // lane ^ 4 = (lane ^ 3) ^ 7: a quad reversal, then the mirror of each half row of 8 -- both full-wave DPP patterns, so the second
     // one folds into the consuming add as its DPP operand (round 6; before: row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and
     // 3, on top of an initialised register -- three moves and a separate add per value, 30 values per transform)
-    r = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xF, 0xF, false);   // quad_perm:[3,2,1,0]
+    r = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xF, 0xF, true);    // quad_perm:[3,2,1,0] (bound_ctrl: every lane is written, no `old` to set up)
     r = __builtin_amdgcn_update_dpp(0, r, 0x141, 0xF, 0xF, false);  // row_half_mirror
   } else if (MASK == 8) {
     r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror:8
