@@ -28,11 +28,14 @@
 #ifndef RN_HP_ATTR
 #define RN_HP_ATTR
 #endif
-extern "C" __global__ void __launch_bounds__(4 * WAVE) RN_HP_ATTR
-RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
+// The body is compiled once per (high-pass applied, int16 input): as run-time flags the two were tested inside the block loop, per
+// float4, and behind those joins the compiler could no longer count the loads in flight -- it waited with vmcnt(0) in front of every
+// block's arithmetic, i.e. for the NEXT block's loads it had just issued: the one-block prefetch hid nothing (round 6, last day).
+template <bool HP_ON, bool IN_S16>
+__device__ __forceinline__ void hp_body(const RnGroupDev &g, const float *__restrict__ in, int slot, int mode) {
   // mode: bit 0 = apply the high-pass (inference); bit 1 = `in` holds int16 samples, converted as the reference's only caller
   // does (examples/rnnoise_demo.c:56: x[i] = tmp[i], short -> float, exact)
-  const int apply_hp = mode & 1, in_s16 = mode & 2;
+  constexpr bool apply_hp = HP_ON, in_s16 = IN_S16;
   // bits 12-13: streams per wave = 64 >> k.  The kernel is bound by how many loads its waves keep in flight (one wave per SIMD at 64 streams
   // per wave and 65,536 streams: each lane's HBM round trips are its own), not by issue: half-empty waves are twice as many waves
   const int spw = WAVE >> ((mode >> 12) & 3);
@@ -199,7 +202,19 @@ RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode
     }
   }
 }
-
+// ONE kernel for the four forms.  (Tried: a kernel of its own for int16 input, so that the float forms keep their 101 registers
+// instead of the 128 of the hungriest form -- slower, 0.147 against 0.135 ms at 65,536 streams: inside the common kernel the scheduler
+// works the float forms to the looser budget too, and that is the faster code.  profiles/r6_hp_specialised.txt)
+extern "C" __global__ void __launch_bounds__(4 * WAVE) RN_HP_ATTR
+RN_HP_KERNEL_NAME(RnGroupDev g, const float *__restrict__ in, int slot, int mode) {
+  if (mode & 2) {
+    if (mode & 1) hp_body<true, true>(g, in, slot, mode);
+    else hp_body<false, true>(g, in, slot, mode);
+  } else {
+    if (mode & 1) hp_body<true, false>(g, in, slot, mode);
+    else hp_body<false, false>(g, in, slot, mode);
+  }
+}
 #ifndef RN_HP_VARIANT_ONLY
 // ---------------------------------------------------------------------------------------------
 // K0 for a handful of streams (the one-stream states behind rnnoise_process_frame, and batches of up to 64 streams): the
@@ -408,8 +423,8 @@ extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s
   // biquad's registers the 64-register budget spills: gone.)
   static const int wpb = [] { const char *e = RN_LAB_ENV("HP_WPB"); return e && atoi(e) == 4 ? 4 : 1; }();  // (A/B: waves per workgroup)
   const int per_block = wpb > 1 ? wpb * WAVE : spw;
-  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + per_block - 1) / per_block), dim3(wpb * WAVE), 0, st, e0, done, *g,
-            static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
+  RN_LAUNCH(slp ? rn_hp_slp_kernel : rn_hp_kernel, dim3((g->n_streams + per_block - 1) / per_block), dim3(wpb * WAVE),
+            0, st, e0, done, *g, static_cast<const float *>(in), slot, 1 | (in_s16 ? 2 : 0) | ab | (spw_shift << 12));
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_hp_passthrough(const RnGroupDev *g, const float *in, int slot, hipStream_t st) {

@@ -58,7 +58,8 @@ def test_register_budgets(built):
     assert dsp["rn_synthesis_kernel"]["vgpr_count"] <= 96 and dsp["rn_synthesis_kernel"]["vgpr_spill_count"] == 0
     assert dsp["rn_synthesis_few_kernel"]["vgpr_spill_count"] == 0
     hp, _ = built["hp_kernel"]
-    assert hp["rn_hp_kernel"]["private_segment_fixed_size"] == 0 and hp["rn_hp_one_kernel"]["private_segment_fixed_size"] == 0
+    for k in ("rn_hp_kernel", "rn_hp_one_kernel"):
+        assert hp[k]["private_segment_fixed_size"] == 0 and hp[k]["vgpr_spill_count"] == 0, (k, hp[k])
     assert hp["rn_hp_kernel"]["vgpr_count"] <= 128  # four waves per SIMD
     gru, _ = built["nn_layers"]
     assert gru["rn_nn_gru_kernel"]["vgpr_count"] <= 256 and gru["rn_nn_gru_kernel"]["vgpr_spill_count"] == 0  # two waves per SIMD
