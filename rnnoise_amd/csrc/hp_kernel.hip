@@ -236,14 +236,14 @@ struct HpOneLds {
 };
 static_assert(864 + 64 + 8 <= RN_PITCH_BUF_SIZE - RN_FRAME_SIZE, "the decimated signal and its pad stay below the new frame");
 
-extern "C" __global__ void __launch_bounds__(WAVE)
-rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
-  __shared__ __attribute__((aligned(16))) HpOneLds L;
-  // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
-  const bool listed = rows.n > 0;
-  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
-  const int s = listed ? RN_ROW_OF(re) : (int)blockIdx.x, slot = listed ? RN_ROW_RING(re) : slot_arg, lane = threadIdx.x;
-  const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO : in + (size_t)s * RN_FRAME_SIZE;
+// (the body once per input type, like hp_body above: behind the run-time test per load the frame's two loads and the three loads of
+//  old samples were each followed by its own s_waitcnt vmcnt(0) -- five serial round trips, two of them to pinned host memory in the
+//  one-frame API, in front of a kernel of ~20 us)
+template <bool IN_S16>
+__device__ __forceinline__ void hp_one_body(HpOneLds &L, const RnGroupDev &g, const float *__restrict__ in, const float *__restrict__ in_row,
+                                            bool listed, int s, int slot, int slot_arg) {
+  constexpr bool in_s16 = IN_S16;
+  const int lane = threadIdx.x;
   const float a0 = -1.99599f, a1 = 0.99600f, b0 = -2.f;
   const double na0 = -(double)a0, na1 = -(double)a1, b0d = (double)b0;
   float m0 = g.mem_hp[2 * s], m1 = g.mem_hp[2 * s + 1];
@@ -277,12 +277,13 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
       p = (p >= RN_XRING_SIZE) ? p - RN_XRING_SIZE : p;
       o[i] = *reinterpret_cast<const float4 *>(xring + p);
     }
+    // (stores at the clamped index too, without a branch: a lane past the end holds the last float4 and rewrites it with its own value.
+    //  Behind a branch per store the compiler sank every load to its store and waited for it there: five round trips one after the other)
 #pragma unroll
     for (int i = 0; i < 2; i++)
-      if (lane + 64 * i < RN_FRAME_SIZE / 4) reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE))[lane + 64 * i] = f[i];
+      reinterpret_cast<float4 *>(L.pb + (RN_PITCH_BUF_SIZE - RN_FRAME_SIZE))[min(lane + 64 * i, RN_FRAME_SIZE / 4 - 1)] = f[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-      if (lane + 64 * i < OLD4) reinterpret_cast<float4 *>(L.pb)[lane + 64 * i] = o[i];
+    for (int i = 0; i < 3; i++) reinterpret_cast<float4 *>(L.pb)[min(lane + 64 * i, OLD4 - 1)] = o[i];
   }
   __syncthreads();
   // rnn_biquad (src/denoise.c:409-419), once per wave: every lane reads the same samples and computes the same states
@@ -377,6 +378,17 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
       for (int k = 0; k < 5; k++) g.debug[(size_t)s * RN_DBG_FLOATS + RN_DBG_AC + k] = ac[k];
     }
   }
+}
+extern "C" __global__ void __launch_bounds__(WAVE)
+rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int in_s16, RnRows rows) {
+  __shared__ __attribute__((aligned(16))) HpOneLds L;
+  // (rows: the launch groups of the one-frame API, rn_dev.h -- the block's stream, ring slot and frame buffer come from the list)
+  const bool listed = rows.n > 0;
+  const uint32_t re = listed ? rows.e[blockIdx.x] : 0u;
+  const int s = listed ? RN_ROW_OF(re) : (int)blockIdx.x, slot = listed ? RN_ROW_RING(re) : slot_arg;
+  const float *in_row = listed ? rows.io + (size_t)s * RN_ROW_IO : in + (size_t)s * RN_FRAME_SIZE;
+  if (in_s16) hp_one_body<true>(L, g, in, in_row, listed, s, slot, slot_arg);
+  else hp_one_body<false>(L, g, in, in_row, listed, s, slot, slot_arg);
 }
 
 
