@@ -392,11 +392,13 @@ rn_hp_one_kernel(RnGroupDev g, const float *__restrict__ in, int slot_arg, int i
 }
 
 
-// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form.  Round 5, 6.9 KB of LDS per wave -- 16 waves per CU, so 4,096 streams
-// are one round: K0 at 1024 / 2048 / 3072 / 4096 / 6144 / 8192 streams 33 / 38 / 48 / 60 / 80 / 99 us against 72 / 72 / 68 / 75 / 78 / 86 us lane =
-// stream (one slow box, one call); with 12.5 KB it was 66 against 59 us at 4,096 and the switch sat at 3,072)
-#define RN_HP_ONE_MAX 5120
-#define RN_HP_ONE_MAX_PIPELINED 3072
+// (up to RN_HP_ONE_MAX streams one wave per stream is the faster form.  With the lane = stream kernel's block loop waiting properly
+// (profiles/r6_hp_specialised.txt) that kernel is one wave's latency chain of ~36 us whatever the batch, from 1,024 to 5,120 streams, and the
+// one-wave form 25 / 35 / 45 / 55 / 65 us at 1,024 / 2,048 / 3,072 / 4,096 / 5,120: the switch sits at 2,048 -- alone on the machine
+// (one frame per call: 0.258 -> 0.239 ms per step at 4,096 streams) and inside pipelined calls (3,072 streams: 20.8 -> 21.1 M frames/s;
+// at 2,048 the one-wave form is the better one by 6 %).  Rounds 5-6 until then: 5,120 / 3,072.)
+#define RN_HP_ONE_MAX 2048
+#define RN_HP_ONE_MAX_PIPELINED 2048
 #define RN_HP_SPW 64  // streams per wave of the lane = stream kernel
 #if RN_INSTRUMENT
 extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restrict__ in, int slot, int mode);  // hp_slp.hip
@@ -405,9 +407,8 @@ extern "C" __global__ void rn_hp_slp_kernel(RnGroupDev g, const float *__restric
 #endif
 extern "C" hipError_t rn_launch_hp(const RnGroupDev *g, const void *in, int in_s16, int slot, hipStream_t st, hipEvent_t e0, hipEvent_t done) {
   // bit 9 of `slot` (batch.cpp): the call is one frame of a PIPELINED multi-frame call -- this kernel then runs on a side stream beside the
-  // analysis and network kernels of other frames, where 4,096 waves with 6.9 KB of LDS each crowd them (4,096 streams: 0.197 against
-  // 0.181 ms per step) while 64 lane-per-stream waves without LDS do not: the switch stays at 3,072 there; alone on the machine (one
-  // frame per call: 0.280 against 0.291 ms) the one-wave form wins up to RN_HP_ONE_MAX
+  // analysis and network kernels of other frames (the two switches are kept apart because they were different ones until round 6's
+  // last day, and may be again)
   static const int one_max_env = [] { const char *e = getenv("RNNOISE_AMD_HP_ONE_MAX"); return e ? atoi(e) : -1; }();  // (A/B runs)
   const bool beside_others = slot & 512;
   slot &= 511;

@@ -15,7 +15,7 @@ def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
         names = [bench.kernel_of(kind, n) for kind in ("highpass", "analysis", "network", "synthesis")]
         # five launches from 16,384 streams up; the four-wave layer kernel once there are more 64-stream groups than CUs
         assert names[2] == ("rn_nn_gru_kernel" if n > 16384 else ("rn_nn_gru_w8_kernel" if n == 16384 else "rn_nn_mfma_kernel"))
-        assert names[0] == ("rn_hp_one_kernel" if n <= 3072 else "rn_hp_kernel")  # one wave per stream up to 3072 streams (pipelined calls)
+        assert names[0] == ("rn_hp_one_kernel" if n <= 2048 else "rn_hp_kernel")  # one wave per stream up to 2048 streams
         for k in names + ["rn_analysis_kernel", "rn_analysis_single_kernel"]:
             if k == "rn_hp_one_kernel":
                 continue  # (no PMC pass at a batch size that runs it: its traffic is reported as null)

@@ -610,7 +610,7 @@ def test_other_stream_schedules_forced(mode):
 
 
 def test_throughput_kernels_at_small_sizes():
-    """Small batches run the latency-oriented kernels by default (rn_hp_one_kernel up to 3072 streams, rn_nn_one_kernel up to
+    """Small batches run the latency-oriented kernels by default (rn_hp_one_kernel up to 2048 streams, rn_nn_one_kernel up to
     512 on the vector path); with both switched off ($RNNOISE_AMD_HP_ONE_MAX / $RNNOISE_AMD_NN_ONE_MAX = 0, read once per
     process) the same cases go through rn_hp_kernel and rn_nn_vector_kernel -- the kernels of larger batches -- and must give
     the same bits; $RNNOISE_AMD_K1_SPW=4 adds the four-stream analysis workgroups of large batches, tails included"""
@@ -633,7 +633,7 @@ def test_throughput_kernels_at_small_sizes():
 
 def test_at_size_kernels_on_small_ragged_batches():
     """The kernels that only LARGE batches take by default -- the four-wave GRU layer kernel (rn_nn_gru_kernel: more 64-stream
-    groups than CUs), the lane-per-stream high-pass (rn_hp_kernel: above 3,072 streams), the four-stream analysis workgroup -- forced
+    groups than CUs), the lane-per-stream high-pass (rn_hp_kernel: above 2,048 streams), the four-stream analysis workgroup -- forced
     onto the small ragged cases ($RNNOISE_AMD_GRU_VARIANT=w4, with the latency kernels off and the layer-wise network from size 0
     up): n = 4 ... 130 streams against the oracle stream by stream, partial tiles, partial groups, partial waves.  The default run of
     the same cases takes the eight-wave form (w8) and the wave-per-stream high-pass; tests/test_gpu_at_size.py has the ragged batch at
