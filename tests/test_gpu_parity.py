@@ -476,6 +476,36 @@ def test_device_resident_path_with_torch_stream(model, blob_default):
     assert_bits_equal(d_vad.cpu().numpy(), want["vad"], "vad")
 
 
+def test_empty_calls_change_nothing(model, blob_default):
+    """A call of ZERO frames (host and device entry points, float and int16) is a successful no-op -- state, later results and
+    the caller's buffers untouched -- and a negative frame count fails without touching anything (the reference has no frame
+    count: examples/rnnoise_demo.c:52-61 simply stops calling; the batched API's empty input is ours to define)."""
+    torch = pytest.importorskip("torch")
+    N, T = 5, 6
+    pcm = synth.batch_pcm(range(N), T)
+    want = oracle_run(blob_default, pcm)
+    b = capi.Batch(model, N)
+    empty = np.zeros((0, N, 480), np.float32)
+    o, v, g = b.process(empty)
+    assert o.shape == (0, N, 480) and v.shape == (0, N) and g.shape == (0, N, 32)
+    a = b.process(pcm[:3])
+    before = [b.export_state(s) for s in range(N)]
+    b.process(empty)
+    b.process_s16(np.zeros((0, N, 480), np.int16))
+    dev = torch.device("cuda:0")
+    d = torch.full((N, 480), 7.0, device=dev)
+    b.process_device(d.data_ptr(), d.data_ptr(), 0, 0, 0)
+    torch.cuda.synchronize()
+    assert (d == 7.0).all()
+    with pytest.raises(RuntimeError):
+        b.process_device(d.data_ptr(), d.data_ptr(), 0, 0, -1)
+    for s in range(N):
+        assert_bits_equal(b.export_state(s), before[s], f"state of stream {s} across empty calls")
+    c = b.process(pcm[3:])
+    for k, name in enumerate(("out", "vad", "gains")):
+        assert_bits_equal(np.concatenate([a[k], c[k]]), want[name], name)
+
+
 # ---- batched MFMA network path (rnnoise_batch_set_nn_path(b, 1)) -------------------------------
 @pytest.mark.parametrize("n,path", [(4, 1), (17, 1), (64, 1), (65, 1), (17, 0), (65, 0), (5, 2), (17, 2), (64, 2), (65, 2), (130, 2)])
 def test_mfma_path_bit_exact(model, blob_default, n, path):
