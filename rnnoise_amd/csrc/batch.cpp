@@ -445,7 +445,7 @@ int batch_process_device_impl(RNNoiseBatch *b, void *d_out_v, const void *d_in_v
       } else {
         TimedLaunch t(b, 1);
         b->img_valid = false;
-        if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop()));
+        if (b->nn_path >= 1) HIP_OK(rn_launch_nn_mfma(&g, &b->m, &b->tb, st, t.start(), t.stop(), !pipelined));
         else if (g.n_streams <= nn_one_max_streams()) HIP_OK(rn_launch_nn_one(&g, &b->m, &b->tb, st, t.start(), t.stop()));
         else HIP_OK(rn_launch_nn_vector(&g, &b->m, &b->tb, st, t.start(), t.stop()));
       }

@@ -16,6 +16,7 @@
 // Results are bit-identical to the vector path and to the oracle.
 #include "nn_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 #define CHUNK 256      // inputs per staged chunk of the dense_out / vad chains
 #define CH_STRIDE 260  // floats per stream and chunk in LDS (16-byte aligned rows, 2-way bank conflicts at most)
@@ -75,6 +76,23 @@ rn_nn_mfma_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 #include "nn_tile_body.inc"
 #undef RN_NN_MODE
 }
+// The same with SIXTEEN waves per tile, for one-frame calls on batches in which every tile has a CU to itself (n_tiles <= CUs: up to
+// 4,096 streams on MI355X).  The tile is a chain of barrier-separated phases, each as long as its slowest wave: the GRU phases give a
+// wave 24 / NWAVES unit tiles (36 MFMAs each, every weight fragment an L2 round trip), conv2 as many row tiles -- 3 with eight waves,
+// 2 with sixteen (waves 8..15 one).  1,024 threads = 4 waves per SIMD at the same <= 128 VGPRs: the workgroup takes every register of
+// its CU, so inside a pipelined multi-frame call -- where at these sizes the analysis and synthesis waves of the neighbouring frames
+// live on the CU's other half -- it is the slower form (4,096 streams: 21.5 against 25.3 M frames/s), and alone the faster one
+// (0.0750 -> 0.0686 ms, one frame per call 0.237 -> 0.2305 ms per step; profiles/r6_late_ab.txt).  Same arithmetic per element, same
+// bits (tests/test_gpu_parity.py runs both forms at every small size).
+#undef NWAVES
+#define NWAVES 16
+extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_mfma16_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
+#define RN_NN_MODE 0
+#include "nn_tile_body.inc"
+#undef RN_NN_MODE
+}
+#undef NWAVES
+#define NWAVES 8
 extern "C" __global__ void __launch_bounds__(NTHREADS) rn_nn_front_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 #define RN_NN_MODE 1
 #include "nn_tile_body.inc"
@@ -97,9 +115,24 @@ rn_nn_front64_kernel(RnGroupDev g, RnModelDev m, RnTablesDev tb) {
 }
 #endif
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, hipStream_t st,
-                                        hipEvent_t e0, hipEvent_t e1) {
+                                        hipEvent_t e0, hipEvent_t e1, int alone) {
   if (!m->conv2.wmf || !g->nn_act || !m->dense_out.fwm || !m->conv1.fwm) return hipErrorNotSupported;
-  RN_LAUNCH(rn_nn_mfma_kernel, dim3((g->n_streams + TS - 1) / TS), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
+  const int n_tiles = (g->n_streams + TS - 1) / TS;
+  // sixteen waves per tile in a call that runs nothing beside the network while every tile has a CU to itself, eight otherwise;
+  // $RNNOISE_AMD_TILE_WAVES = 8 | 16 forces one (same bits: tests run both)
+  static const int forced = [] { const char *e = getenv("RNNOISE_AMD_TILE_WAVES"); return e ? atoi(e) : 0; }();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  static std::atomic<int> cus[64];  // (per-device cache, relaxed: every writer stores the same value)
+  int ncu = cus[dev].load(std::memory_order_relaxed);
+  if (!ncu) {
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    cus[dev].store(ncu, std::memory_order_relaxed);
+  }
+  if (forced == 16 || (forced != 8 && alone && n_tiles <= ncu))
+    RN_LAUNCH(rn_nn_mfma16_kernel, dim3(n_tiles), dim3(1024), 0, st, e0, e1, *g, *m, *tb);
+  else
+    RN_LAUNCH(rn_nn_mfma_kernel, dim3(n_tiles), dim3(NTHREADS), 0, st, e0, e1, *g, *m, *tb);
   return hipGetLastError();
 }
 extern "C" hipError_t rn_launch_nn_gru_layer(const RnGroupDev *g, const RnModelDev *m, const RnTablesDev *tb, int layer, hipStream_t st,

@@ -43,7 +43,7 @@ extern "C" hipError_t rn_launch_nn_vector(const RnGroupDev *, const RnModelDev *
                                           hipEvent_t);
 extern "C" hipError_t rn_launch_nn_one(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t, hipEvent_t);
 extern "C" hipError_t rn_launch_nn_mfma(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t,
-                                        hipEvent_t);
+                                        hipEvent_t, int alone);  // alone: no other kernel of the call runs beside it
 extern "C" hipError_t rn_launch_nn_layers(const RnGroupDev *, const RnModelDev *, const RnTablesDev *, hipStream_t, hipEvent_t[5][2]);
 extern "C" int rn_nn_layers_launches(void);
 extern "C" hipError_t rn_launch_nn_requant(const RnGroupDev *, hipStream_t);

@@ -652,7 +652,9 @@ def test_throughput_kernels_at_small_sizes():
     # ... and with four streams per analysis workgroup (rn_analysis_kernel, the form of batches from 6144 streams up): the batch
     # sizes of these cases are not multiples of four, so the tail workgroup's surplus waves -- which redo the last stream, meet
     # every barrier and lend their arenas to the narrow phases' row and pair passes -- are exercised too
-    env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0", RNNOISE_AMD_K1_SPW="4")
+    # ... and the tile network kernel in its sixteen-wave form (rn_nn_mfma16_kernel: by default only one-frame calls on up to 4,096
+    # streams take it; the multi-frame calls of these cases run the eight-wave form in the default run of the suite)
+    env = dict(os.environ, RNNOISE_AMD_NN_ONE_MAX="0", RNNOISE_AMD_HP_ONE_MAX="0", RNNOISE_AMD_K1_SPW="4", RNNOISE_AMD_TILE_WAVES="16")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, os.path.join(root, "tests", "test_blob_tools.py"), "-k",
                         "test_mfma_path_bit_exact or test_synthetic_models_on_gpu or test_s16_entry_points or test_drop_in_single_stream_api"],

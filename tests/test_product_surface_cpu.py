@@ -37,7 +37,7 @@ def test_the_product_has_two_gru_layer_kernels_and_no_experiment(built):
             "rn_hp_kernel", "rn_hp_one_kernel",
             "rn_analysis_kernel", "rn_analysis_single_kernel", "rn_analysis_rows_kernel", "rn_train_features_kernel",
             "rn_synthesis_kernel", "rn_synthesis_few_kernel",
-            "rn_nn_vector_kernel", "rn_nn_one_kernel", "rn_nn_mfma_kernel", "rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_w8_kernel",
+            "rn_nn_vector_kernel", "rn_nn_one_kernel", "rn_nn_mfma_kernel", "rn_nn_mfma16_kernel", "rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_w8_kernel",
             "rn_nn_dense_kernel", "rn_nn_requant_kernel",
             "rn_state_gather_kernel", "rn_state_scatter_kernel", "rn_copy_to_host_kernel", "rn_release_store_kernel",
         }, (os.path.basename(p), sorted(all_kernels))
