@@ -74,7 +74,7 @@ KERNEL_OF = {"highpass": "rn_hp_kernel", "analysis": "rn_analysis_kernel", "netw
              "synthesis": "rn_synthesis_kernel"}
 # batch.cpp nn_layers_min_streams() / nn_one_max_streams(), hp_kernel.hip RN_HP_ONE_MAX, dsp_kernels.hip RN_K1_MULTI_MIN_STREAMS:
 # the batch sizes at which the library switches kernels (it honours the same environment variables)
-NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "16384"))
+NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "10240"))
 NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
 HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "2048"))  # (hp_kernel.hip: RN_HP_ONE_MAX, pipelined and one-frame calls)
 K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))

@@ -93,7 +93,7 @@ RNNOISE_EXPORT int rnnoise_batch_export_state(RNNoiseBatch *b, int stream, float
 RNNOISE_EXPORT int rnnoise_batch_import_state(RNNoiseBatch *b, int stream, const float *state);
 
 /* Network implementation: 0 = vector path (v_dot4 / FMA chains), 1 = batched MFMA path -- one kernel per 16-stream tile
- * below 16,384 streams, layer by layer (64 streams per GRU workgroup, five launches) from there up --, 2 = the layer-wise
+ * below 10,240 streams, layer by layer (64 streams per GRU workgroup, five launches) from there up --, 2 = the layer-wise
  * MFMA schedule whatever the batch size (tests, A/B runs).  All produce identical bits and share all state: the path may
  * be switched between calls.  Default: 0 up to 512 streams (there path 0 runs as a latency-oriented kernel, one workgroup per
  * stream, which finishes before a 16-stream MFMA tile does), 1 beyond.

@@ -10,14 +10,17 @@ T *carve(uint8_t *&p, size_t count) {
   return r;
 }
 
-// Batches from this size up run the network layer by layer (nn_layers.hip: 64 streams per GRU workgroup); below it the
 }  // namespace
 
-// five launches and the smaller grids cost more than the weight reuse gains.  $RNNOISE_AMD_NN_LAYERS_MIN overrides (A/B runs).
+// Batches from this size up run the network layer by layer (nn_layers.hip: 64 streams per GRU workgroup); below it the five launches
+// and the smaller grids cost more than the weight reuse gains.  The tile kernel holds out while a CU has at most two tiles (8,192
+// streams on 256 CUs: 25.9 against 24.2 M frames/s); with a third its K2 jumps (0.139 -> 0.193 ms at 10,240 streams) and the layer-wise
+// network is ahead -- 27.5 against 25.8 M frames/s at 10,240, 29.5 against 26.2 at 12,288, one frame per call 24.8 against 23.0 M at
+// 10,240 (profiles/r6_late_ab.txt; rounds 3-6 had the switch at 16,384).  $RNNOISE_AMD_NN_LAYERS_MIN overrides (A/B runs).
 int nn_layers_min_streams() {
   static const int v = [] {
     const char *e = getenv("RNNOISE_AMD_NN_LAYERS_MIN");
-    return e ? atoi(e) : 16384;
+    return e ? atoi(e) : 10240;
   }();
   return v;
 }

@@ -1,4 +1,4 @@
-// nn_layers.hip -- K2 for large batches (from 16,384 streams up, batch.cpp: nn_layers_min_streams): the network layer by layer.
+// nn_layers.hip -- K2 for large batches (from 10,240 streams up, batch.cpp: nn_layers_min_streams): the network layer by layer.
 //
 //   rn_nn_front_kernel (nn_mfma.hip)  conv1, conv2 per 16-stream tile; leaves the u8 image of the conv2 output in act_q[0]
 //   rn_nn_gru_kernel    x 3           one GRU layer (src/nnet.c:65-94) for 64 streams per workgroup

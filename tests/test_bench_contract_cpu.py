@@ -11,10 +11,10 @@ import bench  # noqa: E402
 
 
 def test_pmc_record_resolves_every_kernel_name_bench_can_emit():
-    for n in (1024, 4096, 8192, 16384, 65536, 524288 // 8):
+    for n in (1024, 4096, 8192, 10240, 16384, 65536, 524288 // 8):
         names = [bench.kernel_of(kind, n) for kind in ("highpass", "analysis", "network", "synthesis")]
-        # five launches from 16,384 streams up; the four-wave layer kernel once there are more 64-stream groups than CUs
-        assert names[2] == ("rn_nn_gru_kernel" if n > 16384 else ("rn_nn_gru_w8_kernel" if n == 16384 else "rn_nn_mfma_kernel"))
+        # five launches from 10,240 streams up; the four-wave layer kernel once there are more 64-stream groups than CUs
+        assert names[2] == ("rn_nn_gru_kernel" if n > 16384 else ("rn_nn_gru_w8_kernel" if n >= 10240 else "rn_nn_mfma_kernel"))
         assert names[0] == ("rn_hp_one_kernel" if n <= 2048 else "rn_hp_kernel")  # one wave per stream up to 2048 streams
         for k in names + ["rn_analysis_kernel", "rn_analysis_single_kernel"]:
             if k == "rn_hp_one_kernel":

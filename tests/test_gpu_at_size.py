@@ -23,7 +23,7 @@ def _tiled_check(blob, N, calls, silent_stream):
     """N streams = N/32 replicas of a 32-stream block, fed from HBM through rnnoise_batch_process_device in `calls` (frames per
     call) on the batch's DEFAULT schedule -- what bench.py times: multi-frame calls run the three-stream frame pipeline
     (high-pass two frames ahead, analysis(f+1) beside network + synthesis(f)), the 6-slot pitch ring and the 3 spectra slots
-    wrap, call boundaries fall inside the ring, the network runs layer-wise from 16,384 streams up and the analysis kernel
+    wrap, call boundaries fall inside the ring, the network runs layer-wise from 10,240 streams up and the analysis kernel
     four streams per workgroup.  A one-frame call in the middle takes the unpipelined route through the same state."""
     import torch
     T = sum(calls)
@@ -133,8 +133,24 @@ def test_ragged_40037_streams(blob_default, blob_little, which):
 
 
 @pytest.mark.rcp("host")
+def test_ragged_10277_streams_just_above_the_network_switch(blob_default):
+    """The layer-wise network starts at 10,240 streams (batch.cpp: nn_layers_min_streams; 16,384 until round 6's last day): a
+    ragged batch just above the switch -- 10,277 = 16 x 642 + 5 = 64 x 160 + 37, the eight-wave layer kernel (fewer 64-stream groups
+    than CUs) with a partial tile and a partial group -- and, below, the largest batches of the tile kernel on both sides of 8,192
+    streams (two tiles per CU, then three).  Arithmetic under test: src/nnet.c:65-94, src/rnn.c:44-60."""
+    _ragged_check(blob_default, 10277, (4, 1, 3), silent_stream=3)
+
+
+@pytest.mark.rcp("host")
+@pytest.mark.parametrize("n", [8192, 10208])
+def test_the_tile_network_at_its_largest_batches(blob_default, n):
+    _tiled_check(blob_default, n, (3, 1, 2), silent_stream=9)
+
+
+@pytest.mark.rcp("host")
 def test_16384_streams_on_the_host_profile(blob_default):
-    """the smallest batch on the layer-wise network, on the profile a deployed process gets by default (this CPU's rcpps)"""
+    """the largest batch on the eight-wave layer kernel (one 64-stream group per CU), on the profile a deployed process gets by
+    default (this CPU's rcpps)"""
     _tiled_check(blob_default, 16384, (3, 4), silent_stream=5)
 
 
