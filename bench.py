@@ -78,7 +78,7 @@ NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "10240")
 NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
 HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "2048"))  # (hp_kernel.hip: RN_HP_ONE_MAX, pipelined and one-frame calls)
 K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))
-K1_MULTI_MIN_STREAMS = 6144
+K1_MULTI_MIN_STREAMS = 2560
 K3_FEW_MAX_STREAMS = 256
 N_CU = 256
 NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")

@@ -15,7 +15,11 @@
 #include "log10_glibc.h"
 
 #define WAVE 64
-#define RN_K1_MULTI_MIN_STREAMS 6144  // from here on K1_SPW streams share a workgroup (see rn_analysis_single_kernel)
+// from here on K1_SPW streams share a workgroup (see rn_analysis_single_kernel).  6,144 until round 6's last day; since the narrow
+// phases and the follower are shared by the four streams of a workgroup (round 6) that form is ahead from 3,072 streams -- 23.3
+// against 20.8 M frames/s there, 26.4 against 24.5 at 4,096 (one frame per call 0.201 against 0.231 ms), 27.8 against 26.0 at
+// 5,120 -- and level at 2,048 (profiles/r6_late_ab.txt)
+#define RN_K1_MULTI_MIN_STREAMS 2560
 
 // Every LDS arena below belongs to ONE wavefront, and a wavefront's LDS instructions execute in issue order, so the
 // hand-offs between lanes of a wave need no s_barrier: a wavefront-scope fence pins the compiler's ordering and nothing

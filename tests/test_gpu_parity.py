@@ -649,7 +649,7 @@ def test_throughput_kernels_at_small_sizes():
     import sys
     if os.environ.get("RNNOISE_AMD_NN_ONE_MAX"):
         pytest.skip("already inside a forced run")
-    # ... and with four streams per analysis workgroup (rn_analysis_kernel, the form of batches from 6144 streams up): the batch
+    # ... and with four streams per analysis workgroup (rn_analysis_kernel, the form of batches from 2560 streams up): the batch
     # sizes of these cases are not multiples of four, so the tail workgroup's surplus waves -- which redo the last stream, meet
     # every barrier and lend their arenas to the narrow phases' row and pair passes -- are exercised too
     # ... and the tile network kernel in its sixteen-wave form (rn_nn_mfma16_kernel: by default only one-frame calls on up to 4,096
