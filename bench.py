@@ -78,13 +78,14 @@ NN_LAYERS_MIN_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_LAYERS_MIN", "10240")
 NN_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_NN_ONE_MAX", "512"))
 HP_ONE_MAX_STREAMS = int(os.environ.get("RNNOISE_AMD_HP_ONE_MAX", "2048"))  # (hp_kernel.hip: RN_HP_ONE_MAX, pipelined and one-frame calls)
 K1_SPW_FORCE = int(os.environ.get("RNNOISE_AMD_K1_SPW", "0"))
+TILE_WAVES_FORCE = int(os.environ.get("RNNOISE_AMD_TILE_WAVES", "0"))
 K1_MULTI_MIN_STREAMS = 2560
 K3_FEW_MAX_STREAMS = 256
 N_CU = 256
 NN_LAYER_KERNELS = ("rn_nn_front_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_gru_kernel", "rn_nn_dense_kernel")
 
 
-def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
+def kernel_of(kind: str, n_streams: int, nn: str = "mfma", alone: bool = False) -> str:
     """Name of the kernel behind a timed kind (rocprofv3 / PMC tables use it).  The network kind of a large batch is five
     launches timed as one (front, three GRU layers, dense); its PMC record is that of the GRU layer kernel, which is
     three of the five and the longest."""
@@ -92,7 +93,9 @@ def kernel_of(kind: str, n_streams: int, nn: str = "mfma") -> str:
         if nn != "mfma":
             return "rn_nn_one_kernel" if n_streams <= NN_ONE_MAX_STREAMS else "rn_nn_vector_kernel"
         if n_streams < NN_LAYERS_MIN_STREAMS:
-            return "rn_nn_mfma_kernel"
+            # (nn_mfma.hip: sixteen waves per tile in one-frame calls while every tile has a CU to itself; no PMC pass records that form)
+            sixteen = TILE_WAVES_FORCE == 16 or (TILE_WAVES_FORCE != 8 and alone and -(-n_streams // 16) <= N_CU)
+            return "rn_nn_mfma16_kernel" if sixteen else "rn_nn_mfma_kernel"
         # (nn_layers.hip: the four-wave form once there are more 64-stream groups than CUs, the eight-wave one below)
         return "rn_nn_gru_kernel" if -(-n_streams // 64) > N_CU else "rn_nn_gru_w8_kernel"
     if kind == "analysis" and k1_single(n_streams):
@@ -606,7 +609,7 @@ def bench_rank(a) -> dict | None:
         # dominant KERNEL = longest single launch: the layer-wise network is five launches whose durations kernel_ms adds up
         n_launch = {k: (len(NN_LAYER_KERNELS) if k == "network" and a.nn == "mfma" and N >= NN_LAYERS_MIN_STREAMS else 1) for k in kinds}
         dom = max(kinds, key=lambda k: kms[k] / n_launch[k])
-        kname = kernel_of(dom, N, a.nn)
+        kname = kernel_of(dom, N, a.nn, alone=a.frames_per_call == 1)
         # a kind of several launches (the layer-wise network) is represented by its MEAN launch: a fifth of the kind's bytes in a
         # fifth of the kind's time (the library times the five launches separately but reports their sum)
         dom_ms = kms[dom] / n_launch[dom]
